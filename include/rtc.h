@@ -1,0 +1,191 @@
+/*
+ * rtc.h -- C ABI of librtc_amd.so: the MI355X (gfx950) implementation of the per-pixel render path
+ * of anna-hope/ray-tracer-challenge (Camera::render -> World::color_at -> intersect ->
+ * prepare_computations -> shade_hit -> reflected_color / refracted_color).
+ *
+ * The reference boundary is one Rust method, `Camera::render(&self, &World) -> Result<Canvas>`
+ * (ray_tracer/src/camera.rs:64), fed by `World::new(objects, lights)` (world.rs:19-21).  This header
+ * is what a Rust `extern "C"` block binds instead: plain pointers and sizes,
+ * all floating point is IEEE f64, matrices are 4x4 row-major, colours are RGB triples.
+ *
+ * Conventions
+ *   - every function returns RTC_OK (0) or an RTC_ERR_* code; rtc_last_error() gives the text
+ *     (thread-local).  The only error the reference path itself can raise is NonInvertibleMatrix
+ *     (error.rs:3-7) -> RTC_ERR_NON_INVERTIBLE.
+ *   - one scene per handle; a handle is not thread-safe, different handles are independent.
+ *   - the render entry points run on the GPU only: there is no CPU fallback; without a usable HIP
+ *     device they fail with RTC_ERR_NO_DEVICE.
+ *
+ * Citations are `path:line` relative to the reference root.
+ */
+#ifndef RTC_H
+#define RTC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtc_scene rtc_scene;
+
+enum rtc_status {
+    RTC_OK = 0,
+    RTC_ERR_NON_INVERTIBLE = 1, /* RayTracerError::NonInvertibleMatrix, error.rs:3-7 */
+    RTC_ERR_INVALID = 2,        /* bad argument / index / call order */
+    RTC_ERR_NO_DEVICE = 3,      /* no usable HIP device (the product never renders on the CPU) */
+    RTC_ERR_HIP = 4,            /* a HIP runtime call failed */
+    RTC_ERR_STATE = 5,          /* scene not committed / already committed */
+    RTC_ERR_IO = 6,             /* file could not be read / written */
+    RTC_ERR_PARSE = 7,          /* YAML / OBJ syntax or semantic error (parse_scene ParseError) */
+    RTC_ERR_OVERFLOW = 8        /* a per-lane bound of the kernel was exceeded (see rtc_stats.overflow) */
+};
+
+/* ShapeType, shape.rs:27-38.  Triangles are added with rtc_scene_add_triangles, groups with
+ * rtc_scene_begin_group/end_group.  Csg is out of scope (unreachable from YAML). */
+enum rtc_shape_type { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4 };
+
+/* PatternType, pattern.rs:5-15 (Perturbed excluded: arithmetic lives in the un-vendored perlin_noise crate) */
+enum rtc_pattern_type {
+    RTC_PAT_STRIPE = 0,
+    RTC_PAT_GRADIENT = 1,
+    RTC_PAT_RING = 2,
+    RTC_PAT_CHECKER = 3,
+    RTC_PAT_RADIAL = 4,
+    RTC_PAT_SOLID = 5,
+    RTC_PAT_BLENDED = 6,
+    RTC_PAT_TEST = 7 /* pattern.rs:652-676: colour = point; kept for the reference's own known-answer test */
+};
+
+/* Material, material.rs:4-15; defaults material.rs:83-96 (rtc_material_default) */
+typedef struct rtc_material {
+    double color[3];
+    double ambient, diffuse, specular, shininess;
+    double reflectivity, transparency, refractive_index;
+    int32_t casts_shadow;
+    int32_t pattern; /* index from rtc_scene_add_pattern, or -1 for None */
+} rtc_material;
+
+/* Render options.  Zero-initialise and call rtc_render_opts_default(). */
+typedef struct rtc_render_opts {
+    uint32_t depth;      /* bounce budget; the reference uses the literal 5 (camera.rs:80) */
+    uint32_t tile_rows;  /* rows per row tile for multi-GPU sharding (0 = whole image is one tile) */
+    uint32_t tile_index; /* this rank renders tiles t with t % tile_count == tile_index */
+    uint32_t tile_count; /* number of ranks (1 = everything) */
+    uint32_t use_bvh;    /* 0 = auto, 1 = force BVH traversal, 2 = force brute-force linear scan */
+    uint32_t collect_stats; /* 1 = run the counting variant of the kernel and fill the ray/test counters */
+    uint32_t reserved[2];
+} rtc_render_opts;
+
+/* Work counters (filled when collect_stats != 0) and timing of the last launch. */
+typedef struct rtc_stats {
+    uint64_t pixels;          /* active pixels rendered by this call: (hsize-1) x rows */
+    uint64_t primary_rays;    /* one per active pixel */
+    uint64_t shadow_rays;     /* one per (shaded hit x light sample) */
+    uint64_t secondary_rays;  /* reflect + refract rays actually traced ("rays_unique") */
+    uint64_t secondary_rays_reference; /* what the reference traces: subtrees re-traced once per light (Q3) */
+    uint64_t container_passes; /* n1/n2 line passes (not rays) */
+    uint64_t box_tests;
+    uint64_t prim_tests[7];   /* sphere, plane, cube, cylinder, cone, triangle, smooth triangle */
+    uint64_t xform_levels;    /* ray -> object-space transforms applied (33 flops each) */
+    uint64_t shaded_hits;
+    uint64_t light_evals;     /* Material::lighting evaluations */
+    uint64_t schlick_evals;
+    uint64_t refract_evals;
+    uint64_t overflow;        /* lanes that hit the iteration cap (0 in a valid render) */
+    double kernel_ms;         /* HIP-event time of the render kernel on its stream (rtc_render only) */
+    double algorithmic_flops; /* SURVEY.md 8(d) flop table x the counters above */
+} rtc_stats;
+
+const char *rtc_last_error(void);
+const char *rtc_version(void);
+void rtc_material_default(rtc_material *out);   /* Material::default(), material.rs:83-96 */
+void rtc_render_opts_default(rtc_render_opts *out);
+
+/* ---- host math, bit-faithful to the reference (used by loaders / callers that build transforms) ----
+ * matrix.rs:181-266 (builders), :302-326 (multiply), :74-179 (determinant / cofactor inverse),
+ * transformation.rs:3-15 (view transform).  `out` may alias an input. */
+void rtc_matrix_identity(double out[16]);
+void rtc_matrix_translation(double x, double y, double z, double out[16]);
+void rtc_matrix_scaling(double x, double y, double z, double out[16]);
+void rtc_matrix_rotation_x(double radians, double out[16]);
+void rtc_matrix_rotation_y(double radians, double out[16]);
+void rtc_matrix_rotation_z(double radians, double out[16]);
+void rtc_matrix_shearing(double xy, double xz, double yx, double yz, double zx, double zy, double out[16]);
+void rtc_matrix_multiply(const double a[16], const double b[16], double out[16]);
+int rtc_matrix_inverse(const double a[16], double out[16]); /* RTC_ERR_NON_INVERTIBLE iff det == 0.0 */
+void rtc_view_transform(const double from[3], const double to[3], const double up[3], double out[16]);
+
+/* ---- scene construction: replaces World::new + the Shape constructors ---- */
+rtc_scene *rtc_scene_create(void);
+void rtc_scene_destroy(rtc_scene *scene);
+
+/* Camera::new(hsize, vsize, field_of_view, transformation), camera.rs:17-37 */
+int rtc_scene_set_camera(rtc_scene *scene, uint32_t hsize, uint32_t vsize, double field_of_view,
+                         const double view[16]);
+/* PointLight::new, light.rs:33-38 */
+int rtc_scene_add_point_light(rtc_scene *scene, const double position[3], const double intensity[3]);
+/* AreaLight::new, light.rs:80-104 */
+int rtc_scene_add_area_light(rtc_scene *scene, const double corner[3], const double full_uvec[3], uint32_t usteps,
+                             const double full_vvec[3], uint32_t vsteps, const double intensity[3]);
+int rtc_scene_add_material(rtc_scene *scene, const rtc_material *material, uint32_t *out_id);
+/* Pattern constructors, pattern.rs:80-87, 212-219, 286-293, 354-361, 437-444, 508-511, 568-575.
+ * a/b: colours (GRADIENT/RING/RADIAL, SOLID uses a); sub_a/sub_b: pattern ids (STRIPE/CHECKER/BLENDED). */
+int rtc_scene_add_pattern(rtc_scene *scene, int type, const double a[3], const double b[3], int32_t sub_a,
+                          int32_t sub_b, const double transform[16], uint32_t *out_id);
+/* Group::default().with_transformation(T) [.with_material(m)], shape.rs:1900-1928; children are whatever is
+ * added until the matching rtc_scene_end_group (Group::add_child, shape.rs:1951-1958).  material_id < 0 means
+ * `material: None`; the reference's own constructors always carry Some(..) (shape.rs:1909), which only
+ * triangles consult (shape.rs:1520-1532). */
+int rtc_scene_begin_group(rtc_scene *scene, const double transform[16], int32_t material_id);
+int rtc_scene_end_group(rtc_scene *scene);
+/* Sphere/Plane/Cube/Cylinder/Cone::new, shape.rs:179, 498, 653, 873, 1190.  minimum/maximum/closed are used
+ * by cylinders and cones only. */
+int rtc_scene_add_shape(rtc_scene *scene, int type, const double transform[16], uint32_t material_id,
+                        double minimum, double maximum, int closed);
+/* Triangle::new (normals == NULL, shape.rs:1459) or SmoothTriangle::new (shape.rs:1682): n triangles,
+ * points = 9n doubles (p1,p2,p3), normals = 9n doubles (n1,n2,n3).  material_id is the triangles' own
+ * material, used only when the parent group has none. */
+int rtc_scene_add_triangles(rtc_scene *scene, size_t n, const double *points, const double *normals,
+                            uint32_t material_id);
+
+/* Freeze the scene: cofactor inverses (matrix.rs:157-179), depth-first flattening of the shape tree into SoA
+ * device tables, host-built BVH, upload to HIP device `device` (>= 0).  device == -1 performs the host-side
+ * work only (for CPU-side inspection; such a scene cannot render).  Errors: RTC_ERR_NON_INVERTIBLE if any
+ * camera/shape/group/pattern transform has det == 0.0 (the reference raises it lazily on the first ray that
+ * touches the matrix, matrix.rs:157-161; every shape is touched by every ray). */
+int rtc_scene_commit(rtc_scene *scene, int device);
+
+/* ---- the hot path: replaces Camera::render (camera.rs:64-93) ----
+ * rgb_out: vsize*hsize*3 doubles, row-major canvas; like the reference, the last row and the last column
+ * are never rendered and stay black (camera.rs:72,78).  Synchronous.  With tiling options only this rank's
+ * rows are written (the rest of rgb_out is zeroed). */
+int rtc_render(rtc_scene *scene, const rtc_render_opts *opts, double *rgb_out, rtc_stats *stats);
+
+/* Device-resident variant for callers that own device memory and a stream (torch, RCCL pipelines):
+ * d_rgb is a DEVICE pointer to rtc_local_rows(...)*hsize*3 doubles; this rank's rows are stored compactly in
+ * ascending canvas-row order (every row, including an all-black last canvas row if it is owned).
+ * Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream); allocates nothing. */
+int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream);
+/* Number of canvas rows owned by (tile_index, tile_count, tile_rows) and their canvas row numbers. */
+uint32_t rtc_local_rows(uint32_t vsize, uint32_t tile_rows, uint32_t tile_index, uint32_t tile_count);
+int rtc_local_row_map(uint32_t vsize, uint32_t tile_rows, uint32_t tile_index, uint32_t tile_count,
+                      uint32_t *rows_out, uint32_t cap);
+/* Counters of the most recent collect_stats launch on this scene (synchronises the device). */
+int rtc_scene_last_stats(rtc_scene *scene, rtc_stats *stats);
+
+/* ---- introspection of the committed scene (host side) ---- */
+typedef struct rtc_scene_info {
+    uint32_t hsize, vsize;
+    uint32_t n_prims, n_unbounded, n_bvh_nodes, n_xforms, n_materials, n_lights, n_patterns, n_triangles;
+    uint32_t bvh_max_depth, bvh_max_leaf;
+    uint32_t committed, device;
+    uint64_t device_bytes;
+} rtc_scene_info;
+int rtc_scene_get_info(rtc_scene *scene, rtc_scene_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,456 @@
+// rtc_api.cpp -- the extern "C" boundary declared in include/rtc.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "rtc_scene.h"
+
+using namespace rtc;
+
+namespace rtc {
+const char *last_error();
+}
+
+struct rtc_scene {
+    Scene s;
+};
+
+extern "C" {
+
+const char *rtc_last_error(void) { return rtc::last_error(); }
+const char *rtc_version(void) { return "rtc_amd 0.1 (gfx950, strict fp64)"; }
+
+void rtc_material_default(rtc_material *m) {
+    // material.rs:83-96
+    m->color[0] = m->color[1] = m->color[2] = 1.0;
+    m->ambient = 0.1, m->diffuse = 0.9, m->specular = 0.9, m->shininess = 200.0;
+    m->reflectivity = 0.0, m->transparency = 0.0, m->refractive_index = 1.0;
+    m->casts_shadow = 1;
+    m->pattern = -1;
+}
+
+void rtc_render_opts_default(rtc_render_opts *o) {
+    std::memset(o, 0, sizeof *o);
+    o->depth = 5;  // camera.rs:80
+    o->tile_count = 1;
+}
+
+// ---- host math ---------------------------------------------------------------------------
+void rtc_matrix_identity(double out[16]) { Mat4::identity().to16(out); }
+void rtc_matrix_translation(double x, double y, double z, double out[16]) { mat_translation(x, y, z).to16(out); }
+void rtc_matrix_scaling(double x, double y, double z, double out[16]) { mat_scaling(x, y, z).to16(out); }
+void rtc_matrix_rotation_x(double r, double out[16]) { mat_rotation_x(r).to16(out); }
+void rtc_matrix_rotation_y(double r, double out[16]) { mat_rotation_y(r).to16(out); }
+void rtc_matrix_rotation_z(double r, double out[16]) { mat_rotation_z(r).to16(out); }
+void rtc_matrix_shearing(double xy, double xz, double yx, double yz, double zx, double zy, double out[16]) {
+    mat_shearing(xy, xz, yx, yz, zx, zy).to16(out);
+}
+void rtc_matrix_multiply(const double a[16], const double b[16], double out[16]) {
+    mat_mul(Mat4::from16(a), Mat4::from16(b)).to16(out);
+}
+int rtc_matrix_inverse(const double a[16], double out[16]) {
+    Mat4 inv;
+    if (!mat_inverse(Mat4::from16(a), inv)) {
+        set_error("matrix is not invertible (determinant == 0)");
+        return RTC_ERR_NON_INVERTIBLE;
+    }
+    inv.to16(out);
+    return RTC_OK;
+}
+void rtc_view_transform(const double from[3], const double to[3], const double up[3], double out[16]) {
+    mat_view({from[0], from[1], from[2]}, {to[0], to[1], to[2]}, {up[0], up[1], up[2]}).to16(out);
+}
+
+// ---- scene construction --------------------------------------------------------------------
+rtc_scene *rtc_scene_create(void) { return new (std::nothrow) rtc_scene(); }
+void rtc_scene_destroy(rtc_scene *scene) { delete scene; }
+
+#define CHECK_SCENE(sc)                      \
+    if (!(sc)) {                             \
+        set_error("scene handle is NULL");   \
+        return RTC_ERR_INVALID;              \
+    }
+#define CHECK_OPEN(sc)                                        \
+    CHECK_SCENE(sc)                                           \
+    if ((sc)->s.committed) {                                  \
+        set_error("scene is committed and can not be edited"); \
+        return RTC_ERR_STATE;                                 \
+    }
+
+int rtc_scene_set_camera(rtc_scene *scene, uint32_t hsize, uint32_t vsize, double fov, const double view[16]) {
+    CHECK_OPEN(scene)
+    if (hsize == 0 || vsize == 0) {
+        set_error("camera hsize/vsize must be positive");
+        return RTC_ERR_INVALID;
+    }
+    Scene &s = scene->s;
+    s.has_camera = true;
+    s.hsize = hsize, s.vsize = vsize, s.fov = fov;
+    s.view = view ? Mat4::from16(view) : Mat4::identity();
+    return RTC_OK;
+}
+
+int rtc_scene_add_point_light(rtc_scene *scene, const double position[3], const double intensity[3]) {
+    CHECK_OPEN(scene)
+    DLight l{};
+    for (int i = 0; i < 3; i++) l.position[i] = position[i], l.intensity[i] = intensity[i];
+    l.samples = 1;
+    scene->s.lights.push_back(l);
+    return RTC_OK;
+}
+
+int rtc_scene_add_area_light(rtc_scene *scene, const double corner[3], const double full_uvec[3], uint32_t usteps,
+                             const double full_vvec[3], uint32_t vsteps, const double intensity[3]) {
+    CHECK_OPEN(scene)
+    // light.rs:80-104
+    DLight l{};
+    l.is_area = 1;
+    l.usteps = usteps, l.vsteps = vsteps, l.samples = usteps * vsteps;
+    for (int i = 0; i < 3; i++) {
+        l.corner[i] = corner[i];
+        l.uvec[i] = full_uvec[i] / (double)usteps;
+        l.vvec[i] = full_vvec[i] / (double)vsteps;
+        l.position[i] = (full_uvec[i] + full_vvec[i]) / 2.;  // Q12: corner is not added (light.rs:91-92)
+        l.intensity[i] = intensity[i];
+    }
+    scene->s.lights.push_back(l);
+    return RTC_OK;
+}
+
+int rtc_scene_add_material(rtc_scene *scene, const rtc_material *m, uint32_t *out_id) {
+    CHECK_OPEN(scene)
+    if (!m) {
+        set_error("material is NULL");
+        return RTC_ERR_INVALID;
+    }
+    if (out_id) *out_id = (uint32_t)scene->s.materials.size();
+    scene->s.materials.push_back(*m);
+    return RTC_OK;
+}
+
+int rtc_scene_add_pattern(rtc_scene *scene, int type, const double a[3], const double b[3], int32_t sub_a,
+                          int32_t sub_b, const double transform[16], uint32_t *out_id) {
+    CHECK_OPEN(scene)
+    Scene &s = scene->s;
+    if (type < RTC_PAT_STRIPE || type > RTC_PAT_TEST) {
+        set_error("unknown pattern type %d", type);
+        return RTC_ERR_INVALID;
+    }
+    const bool needs_sub = type == RTC_PAT_STRIPE || type == RTC_PAT_CHECKER || type == RTC_PAT_BLENDED;
+    const int32_t n = (int32_t)s.patterns.size();
+    if (needs_sub && (sub_a < 0 || sub_a >= n || sub_b < 0 || sub_b >= n)) {
+        set_error("pattern type %d needs two existing sub-pattern ids", type);
+        return RTC_ERR_INVALID;
+    }
+    HostPattern p{};
+    p.kind = type, p.sub_a = sub_a, p.sub_b = sub_b;
+    for (int i = 0; i < 3; i++) p.a[i] = a ? a[i] : 1.0, p.b[i] = b ? b[i] : 0.0;
+    p.transform = transform ? Mat4::from16(transform) : Mat4::identity();
+    if (out_id) *out_id = (uint32_t)n;
+    s.patterns.push_back(p);
+    return RTC_OK;
+}
+
+int rtc_scene_begin_group(rtc_scene *scene, const double transform[16], int32_t material_id) {
+    CHECK_OPEN(scene)
+    Item it;
+    it.kind = Item::GROUP;
+    it.transform = transform ? Mat4::from16(transform) : Mat4::identity();
+    it.material = material_id;
+    const int idx = scene->s.add_item(std::move(it));
+    scene->s.open_groups.push_back(idx);
+    return RTC_OK;
+}
+
+int rtc_scene_end_group(rtc_scene *scene) {
+    CHECK_OPEN(scene)
+    if (scene->s.open_groups.empty()) {
+        set_error("rtc_scene_end_group without a matching rtc_scene_begin_group");
+        return RTC_ERR_STATE;
+    }
+    scene->s.open_groups.pop_back();
+    return RTC_OK;
+}
+
+int rtc_scene_add_shape(rtc_scene *scene, int type, const double transform[16], uint32_t material_id,
+                        double minimum, double maximum, int closed) {
+    CHECK_OPEN(scene)
+    if (type < RTC_SPHERE || type > RTC_CONE) {
+        set_error("unknown shape type %d", type);
+        return RTC_ERR_INVALID;
+    }
+    Item it;
+    it.kind = Item::SHAPE;
+    it.type = type;
+    it.transform = transform ? Mat4::from16(transform) : Mat4::identity();
+    it.material = (int32_t)material_id;
+    it.minimum = minimum, it.maximum = maximum, it.closed = closed ? 1 : 0;
+    scene->s.add_item(std::move(it));
+    return RTC_OK;
+}
+
+int rtc_scene_add_triangles(rtc_scene *scene, size_t n, const double *points, const double *normals,
+                            uint32_t material_id) {
+    CHECK_OPEN(scene)
+    if (n == 0) return RTC_OK;
+    if (!points) {
+        set_error("points is NULL");
+        return RTC_ERR_INVALID;
+    }
+    Item it;
+    it.kind = Item::TRIANGLES;
+    it.material = (int32_t)material_id;
+    it.points.assign(points, points + 9 * n);
+    if (normals) it.normals.assign(normals, normals + 9 * n);
+    scene->s.add_item(std::move(it));
+    return RTC_OK;
+}
+
+int rtc_scene_commit(rtc_scene *scene, int device) {
+    CHECK_SCENE(scene)
+    return scene->s.commit(device);
+}
+
+// ---- render ----------------------------------------------------------------------------------
+
+uint32_t rtc_local_rows(uint32_t vsize, uint32_t tile_rows, uint32_t tile_index, uint32_t tile_count) {
+    return local_rows(vsize, tile_rows, tile_index, tile_count);
+}
+
+int rtc_local_row_map(uint32_t vsize, uint32_t tile_rows, uint32_t tile_index, uint32_t tile_count,
+                      uint32_t *rows_out, uint32_t cap) {
+    if (tile_count == 0) tile_count = 1;
+    if (tile_rows == 0 || tile_rows > vsize) tile_rows = vsize ? vsize : 1;
+    const uint32_t ntiles = (vsize + tile_rows - 1) / tile_rows;
+    uint32_t n = 0;
+    for (uint32_t t = tile_index; t < ntiles; t += tile_count)
+        for (uint32_t r = t * tile_rows; r < std::min(vsize, (t + 1) * tile_rows); r++) {
+            if (n < cap && rows_out) rows_out[n] = r;
+            n++;
+        }
+    return (int)n;
+}
+
+static int resolve_params(Scene &s, const rtc_render_opts *opts_in, DRenderParams &p, rtc_render_opts &o) {
+    if (opts_in)
+        o = *opts_in;
+    else
+        rtc_render_opts_default(&o);
+    if (!s.committed || s.device < 0) {
+        set_error("scene is not committed to a HIP device; librtc_amd renders on the GPU only");
+        return s.committed ? RTC_ERR_NO_DEVICE : RTC_ERR_STATE;
+    }
+    if (o.tile_count == 0) o.tile_count = 1;
+    if (o.tile_index >= o.tile_count) {
+        set_error("tile_index %u >= tile_count %u", o.tile_index, o.tile_count);
+        return RTC_ERR_INVALID;
+    }
+    if (o.tile_rows == 0 || o.tile_rows > s.vsize) {
+        if (o.tile_count > 1 && o.tile_rows == 0) {
+            set_error("tile_rows must be set when tile_count > 1");
+            return RTC_ERR_INVALID;
+        }
+        o.tile_rows = s.vsize;
+    }
+    if (o.depth > 64) {
+        set_error("depth %u exceeds the supported bounce budget (64)", o.depth);
+        return RTC_ERR_INVALID;
+    }
+    p = DRenderParams{};
+    p.depth = o.depth;
+    p.tile_rows = o.tile_rows, p.tile_index = o.tile_index, p.tile_count = o.tile_count;
+    p.local_rows = local_rows(s.vsize, o.tile_rows, o.tile_index, o.tile_count);
+    // auto: the BVH pays as soon as a few bounded primitives exist
+    const size_t bounded = s.prims.size() - s.unbounded.size();
+    p.use_bvh = (o.use_bvh == 1) ? 1u : (o.use_bvh == 2) ? 0u : (bounded > 4 ? 1u : 0u);
+    p.tiles_x = (s.hsize + 7u) / 8u;
+    p.tiles_y = (p.local_rows + 7u) / 8u;
+    // the explicit per-lane stack holds one pending refraction per distinct `remaining` value
+    if (o.depth > 8) {
+        set_error("depth %u exceeds the per-lane pending stack (8)", o.depth);
+        return RTC_ERR_INVALID;
+    }
+    return RTC_OK;
+}
+
+static void fill_stats(Scene &s, const std::vector<uint64_t> &c, rtc_stats &st) {
+    st.primary_rays = c[ST_PRIMARY];
+    st.shadow_rays = c[ST_SHADOW];
+    st.secondary_rays = c[ST_SECONDARY];
+    st.secondary_rays_reference = c[ST_SECONDARY_REF];
+    st.container_passes = c[ST_CONTAINER];
+    st.box_tests = c[ST_BOX];
+    for (int i = 0; i < 7; i++) st.prim_tests[i] = c[ST_PRIM0 + i];
+    st.xform_levels = c[ST_XFORM];
+    st.shaded_hits = c[ST_SHADED];
+    st.light_evals = c[ST_LIGHT];
+    st.schlick_evals = c[ST_SCHLICK];
+    st.refract_evals = c[ST_REFRACT];
+    st.overflow = c[ST_OVERFLOW];
+    // SURVEY.md 8(d) flop table (+,-,*,/,sqrt,pow = 1 each)
+    double cyl = 26, cone = 32;
+    {
+        double ncyl = 0, ncyl_closed = 0, ncone = 0, ncone_closed = 0;
+        for (const DPrim &p : s.prims) {
+            if (p.type == PT_CYLINDER) ncyl++, ncyl_closed += p.closed ? 1 : 0;
+            if (p.type == PT_CONE) ncone++, ncone_closed += p.closed ? 1 : 0;
+        }
+        if (ncyl > 0) cyl = 26 + 18 * (ncyl_closed / ncyl);
+        if (ncone > 0) cone = 32 + 18 * (ncone_closed / ncone);
+    }
+    const double per_type[7] = {27, 1, 12, cyl, cone, 46, 46};
+    double f = 33.0 * (double)st.xform_levels + 12.0 * (double)st.box_tests + 79.0 * (double)st.shaded_hits +
+               67.0 * (double)st.light_evals + 18.0 * (double)st.shadow_rays + 25.0 * (double)st.schlick_evals +
+               26.0 * (double)st.refract_evals;
+    for (int i = 0; i < 7; i++) f += per_type[i] * (double)st.prim_tests[i];
+    st.algorithmic_flops = f;
+}
+
+int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream) {
+    CHECK_SCENE(scene)
+    Scene &s = scene->s;
+    DRenderParams p;
+    rtc_render_opts o;
+    int rc = resolve_params(s, opts, p, o);
+    if (rc) return rc;
+    if (!d_rgb) {
+        set_error("d_rgb is NULL");
+        return RTC_ERR_INVALID;
+    }
+    if (p.local_rows == 0) return RTC_OK;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != s.device) {
+        if (hipSetDevice(s.device) != hipSuccess) {
+            set_error("hipSetDevice(%d) failed", s.device);
+            return RTC_ERR_HIP;
+        }
+    }
+    if (o.collect_stats) {
+        if (hipMemsetAsync(s.d_stats, 0, sizeof(uint64_t) * ST_COUNT, (hipStream_t)hip_stream) != hipSuccess) {
+            set_error("hipMemsetAsync(stats) failed");
+            return RTC_ERR_HIP;
+        }
+        s.have_last_stats = true;
+        std::memset(&s.last_stats, 0, sizeof s.last_stats);
+        s.last_stats.pixels = (uint64_t)(s.hsize - 1) * 0;  // filled by rtc_scene_last_stats
+    }
+    return launch_render(s.dscene, p, d_rgb, s.d_stats, o.collect_stats != 0, hip_stream);
+}
+
+int rtc_scene_last_stats(rtc_scene *scene, rtc_stats *stats) {
+    CHECK_SCENE(scene)
+    Scene &s = scene->s;
+    if (!s.committed || s.device < 0 || !s.d_stats) {
+        set_error("scene is not committed to a device");
+        return RTC_ERR_STATE;
+    }
+    if (!stats) return RTC_ERR_INVALID;
+    (void)hipSetDevice(s.device);
+    if (hipDeviceSynchronize() != hipSuccess) {
+        set_error("hipDeviceSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
+        return RTC_ERR_HIP;
+    }
+    std::vector<uint64_t> c(ST_COUNT, 0);
+    if (hipMemcpy(c.data(), s.d_stats, sizeof(uint64_t) * ST_COUNT, hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("hipMemcpy(stats) failed");
+        return RTC_ERR_HIP;
+    }
+    rtc_stats st{};
+    fill_stats(s, c, st);
+    st.pixels = st.primary_rays;
+    st.kernel_ms = s.last_stats.kernel_ms;
+    *stats = st;
+    return st.overflow ? RTC_ERR_OVERFLOW : RTC_OK;
+}
+
+int rtc_render(rtc_scene *scene, const rtc_render_opts *opts, double *rgb_out, rtc_stats *stats) {
+    CHECK_SCENE(scene)
+    Scene &s = scene->s;
+    DRenderParams p;
+    rtc_render_opts o;
+    int rc = resolve_params(s, opts, p, o);
+    if (rc) return rc;
+    if (!rgb_out) {
+        set_error("rgb_out is NULL");
+        return RTC_ERR_INVALID;
+    }
+    if (hipSetDevice(s.device) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed", s.device);
+        return RTC_ERR_HIP;
+    }
+    const size_t row_doubles = (size_t)s.hsize * 3;
+    std::memset(rgb_out, 0, sizeof(double) * row_doubles * s.vsize);  // Canvas::new: all black (canvas.rs:14-29)
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (p.local_rows == 0) return RTC_OK;
+    double *d_rgb = nullptr;
+    const size_t bytes = sizeof(double) * row_doubles * p.local_rows;
+    if (hipMalloc((void **)&d_rgb, bytes) != hipSuccess) {
+        set_error("hipMalloc(%zu) for the canvas failed", bytes);
+        return RTC_ERR_HIP;
+    }
+    hipStream_t st = nullptr;
+    if (o.collect_stats) (void)hipMemsetAsync(s.d_stats, 0, sizeof(uint64_t) * ST_COUNT, st);
+    (void)hipEventRecord((hipEvent_t)s.ev_start, st);
+    rc = launch_render(s.dscene, p, d_rgb, s.d_stats, o.collect_stats != 0, st);
+    (void)hipEventRecord((hipEvent_t)s.ev_stop, st);
+    if (rc == RTC_OK) {
+        const hipError_t e = hipEventSynchronize((hipEvent_t)s.ev_stop);
+        if (e != hipSuccess) {
+            set_error("render kernel failed: %s", hipGetErrorString(e));
+            rc = RTC_ERR_HIP;
+        }
+    }
+    float ms = 0.f;
+    if (rc == RTC_OK) (void)hipEventElapsedTime(&ms, (hipEvent_t)s.ev_start, (hipEvent_t)s.ev_stop);
+    s.last_stats.kernel_ms = ms;
+    if (rc == RTC_OK) {
+        std::vector<double> host(row_doubles * p.local_rows);
+        if (hipMemcpy(host.data(), d_rgb, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+            set_error("hipMemcpy D2H of the canvas failed");
+            rc = RTC_ERR_HIP;
+        } else {
+            std::vector<uint32_t> rows(p.local_rows);
+            rtc_local_row_map(s.vsize, o.tile_rows, o.tile_index, o.tile_count, rows.data(), p.local_rows);
+            for (uint32_t l = 0; l < p.local_rows; l++)
+                std::memcpy(rgb_out + (size_t)rows[l] * row_doubles, host.data() + (size_t)l * row_doubles,
+                            sizeof(double) * row_doubles);
+        }
+    }
+    (void)hipFree(d_rgb);
+    if (rc == RTC_OK && stats) {
+        if (o.collect_stats) {
+            s.have_last_stats = true;
+            rc = rtc_scene_last_stats(scene, stats);
+        } else {
+            stats->kernel_ms = ms;
+        }
+    }
+    return rc;
+}
+
+int rtc_scene_get_info(rtc_scene *scene, rtc_scene_info *out) {
+    CHECK_SCENE(scene)
+    if (!out) return RTC_ERR_INVALID;
+    Scene &s = scene->s;
+    std::memset(out, 0, sizeof *out);
+    out->hsize = s.hsize, out->vsize = s.vsize;
+    out->n_prims = (uint32_t)s.prims.size();
+    out->n_unbounded = (uint32_t)s.unbounded.size();
+    out->n_bvh_nodes = (uint32_t)s.bvh.size();
+    out->n_xforms = (uint32_t)s.xforms.size();
+    out->n_materials = (uint32_t)s.materials.size();
+    out->n_lights = (uint32_t)s.lights.size();
+    out->n_patterns = (uint32_t)s.patterns.size();
+    out->n_triangles = (uint32_t)s.tris.size();
+    out->bvh_max_depth = s.bvh_max_depth, out->bvh_max_leaf = s.bvh_max_leaf;
+    out->committed = s.committed ? 1 : 0;
+    out->device = (uint32_t)s.device;
+    out->device_bytes = s.device_bytes;
+    return RTC_OK;
+}
+
+}  // extern "C"

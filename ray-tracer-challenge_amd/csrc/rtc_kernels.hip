@@ -1,0 +1,888 @@
+// rtc_kernels.hip -- the per-pixel render path as one iterative HIP megakernel for gfx950 (MI355X).
+//
+// Replaces (reference, ray_tracer/src): camera.rs:41-93 (ray_for_pixel, render), world.rs:30-147 (color_at,
+// shade_hit, is_shadowed, reflected_color, refracted_color), world.rs:176-186 + shape.rs local_intersect
+// functions, intersection.rs:66-90,123-219 (schlick, prepare_computations, hit), material.rs:20-75 (lighting),
+// light.rs:49-125.
+//
+// Design:
+//   * one lane = one pixel, one wave = one 8x8 pixel tile, FP64 throughout, compiled with -ffp-contract=off so
+//     every a*b+c rounds twice exactly like the reference's (never contracted) Rust arithmetic;
+//   * the recursion of color_at is an iterative loop: a ray carries a scalar throughput weight, the reflect
+//     child (remaining-1) is followed immediately, the refract child (remaining unchanged, world.rs:142) is
+//     pushed on a 5-entry per-lane stack -- at most one pending entry per distinct `remaining` value;
+//   * closest hit = linear scan of the unbounded primitives + ordered traversal of a host-built binary BVH
+//     whose per-lane stack lives in LDS ([entry][lane] layout, bank-conflict free);
+//   * n1/n2 (intersection.rs:150-179) are computed by a second pass over the whole line t in (-inf, t_hit)
+//     in streaming form: the container list's last element is the primitive with an odd number of crossings
+//     before the hit whose last crossing is latest (see container_visit()).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "rtc_scene.h"
+#include "rtc_types.h"
+
+namespace rtc {
+
+#define RTC_EPS 1e-5  // lib.rs:24
+#define RTC_WAVE 64
+#define RTC_BVH_STACK 32
+#define RTC_MAX_DEPTH_STACK 8
+#define RTC_MAX_RAYS_PER_PIXEL 65536
+
+struct V3 {
+    double x, y, z;
+};
+struct Ray {
+    V3 o, d;
+};
+
+#define DEV __device__ __forceinline__
+
+DEV V3 mk(double x, double y, double z) {
+    V3 r;
+    r.x = x, r.y = y, r.z = z;
+    return r;
+}
+DEV V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+DEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+DEV V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+DEV V3 cmul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }  // color.rs:83-93
+DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // tuple.rs:110-112
+DEV V3 cross(V3 a, V3 b) {                                               // tuple.rs:114-120
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+DEV double magnitude(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // tuple.rs:96-99
+DEV V3 normalize(V3 a) {  // tuple.rs:101-108: three divisions
+    const double m = magnitude(a);
+    return mk(a.x / m, a.y / m, a.z / m);
+}
+DEV V3 reflect(V3 v, V3 n) {  // tuple.rs:122-124: self - (normal * 2.) * self.dot(normal)
+    const double d = dot(v, n);
+    return v - (n * 2.) * d;
+}
+DEV bool approx_zero(double a) { return fabs(a - 0.) < RTC_EPS; }  // lib.rs:26-29 equal(a, 0.)
+
+// matrix.rs:328-346 / 348-365 on a 3x4 row-major inverse
+DEV V3 xf_point(const double *m, V3 p) {
+    return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+DEV V3 xf_vector(const double *m, V3 v) {
+    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+              m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+// transpose(inverse) * n, shape.rs:95
+DEV V3 xf_normal(const double *m, V3 n) {
+    return mk(m[0] * n.x + m[4] * n.y + m[8] * n.z, m[1] * n.x + m[5] * n.y + m[9] * n.z,
+              m[2] * n.x + m[6] * n.y + m[10] * n.z);
+}
+
+// f64::total_cmp key.  A NaN produced by 0/0 on the reference's x86 host is the negative "default NaN";
+// gfx950 produces the positive one, so NaNs are keyed as x86 would order them (below -inf).
+DEV long long total_key(double x) {
+    if (x != x) return (long long)0x8000000000000001LL;
+    long long b = __double_as_longlong(x);
+    b ^= (long long)(((unsigned long long)(b >> 63)) >> 1);
+    return b;
+}
+DEV double max3_total(double a, double b, double c) {  // Iterator::max_by(total_cmp): last maximum
+    double m = a;
+    if (total_key(b) >= total_key(m)) m = b;
+    if (total_key(c) >= total_key(m)) m = c;
+    return m;
+}
+DEV double min3_total(double a, double b, double c) {  // Iterator::min_by(total_cmp): first minimum
+    double m = a;
+    if (total_key(b) < total_key(m)) m = b;
+    if (total_key(c) < total_key(m)) m = c;
+    return m;
+}
+
+// Up to four intersection records of one primitive, in the order the reference pushes them.
+struct Recs {
+    double t0, t1, t2, t3;
+    double u, v;
+    unsigned mask;
+};
+
+// ---------------------------------------------------------------------------------------------
+// local_intersect functions (object-space ray)
+// ---------------------------------------------------------------------------------------------
+
+// shape.rs:218-239
+DEV void isect_sphere(const Ray &r, Recs &o) {
+    const V3 s2r = r.o - mk(0., 0., 0.);
+    const double a = dot(r.d, r.d);
+    const double b = 2. * dot(r.d, s2r);
+    const double c = dot(s2r, s2r) - 1.;
+    const double disc = b * b - 4. * a * c;
+    if (disc < 0.) return;
+    const double sq = sqrt(disc);
+    o.t0 = (-b - sq) / (2. * a);
+    o.t1 = (-b + sq) / (2. * a);
+    o.mask = 3u;
+}
+
+// shape.rs:510-517
+DEV void isect_plane(const Ray &r, Recs &o) {
+    if (fabs(r.d.y) < RTC_EPS) return;
+    o.t0 = -r.o.y / r.d.y;
+    o.mask = 1u;
+}
+
+// shape.rs:708-720 (Q9: divides by a zero direction on purpose)
+DEV void cube_axis(double origin, double direction, double &tmin, double &tmax) {
+    double a = (-1. - origin) / direction;
+    double b = (1. - origin) / direction;
+    if (a > b) {
+        const double t = a;
+        a = b;
+        b = t;
+    }
+    tmin = a, tmax = b;
+}
+// shape.rs:665-704
+DEV void isect_cube(const Ray &r, Recs &o) {
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    double xmin, xmax, ymin, ymax, zmin, zmax;
+    cube_axis(r.o.x, r.d.x, xmin, xmax);
+    if (xmin == inf || xmax == -inf) return;
+    cube_axis(r.o.y, r.d.y, ymin, ymax);
+    if (ymin == inf || ymax == -inf) return;
+    cube_axis(r.o.z, r.d.z, zmin, zmax);
+    const double tmin = max3_total(xmin, ymin, zmin);
+    const double tmax = min3_total(xmax, ymax, zmax);
+    if (tmin > tmax) return;
+    o.t0 = tmin, o.t1 = tmax;
+    o.mask = 3u;
+}
+
+// intersection.rs:34-39 (Q7: `<= radius`, not radius^2)
+DEV bool check_cap(const Ray &r, double t, double radius) {
+    const double x = r.o.x + t * r.d.x;
+    const double z = r.o.z + t * r.d.z;
+    return (x * x + z * z) <= radius;
+}
+
+// shape.rs:895-959
+DEV void isect_cylinder(const Ray &r, double minimum, double maximum, int closed, Recs &o) {
+    const double a = r.d.x * r.d.x + r.d.z * r.d.z;
+    bool side = !approx_zero(a);
+    if (side) {
+        const double b = 2. * r.o.x * r.d.x + 2. * r.o.z * r.d.z;
+        const double c = r.o.x * r.o.x + r.o.z * r.o.z - 1.;
+        const double disc = b * b - 4. * a * c;
+        if (disc < 0.) return;  // Q10: caps are not tested either
+        const double sq = sqrt(disc);
+        double t0 = (-b - sq) / (2. * a);
+        double t1 = (-b + sq) / (2. * a);
+        if (t0 > t1) {
+            const double t = t0;
+            t0 = t1;
+            t1 = t;
+        }
+        const double y0 = r.o.y + t0 * r.d.y;
+        if (minimum < y0 && y0 < maximum) o.t0 = t0, o.mask |= 1u;
+        const double y1 = r.o.y + t1 * r.d.y;
+        if (minimum < y1 && y1 < maximum) o.t1 = t1, o.mask |= 2u;
+    }
+    // intersect_caps, shape.rs:938-959
+    if (!closed || approx_zero(r.d.y)) return;
+    double t = (minimum - r.o.y) / r.d.y;
+    if (check_cap(r, t, 1.)) o.t2 = t, o.mask |= 4u;
+    t = (maximum - r.o.y) / r.d.y;
+    if (check_cap(r, t, 1.)) o.t3 = t, o.mask |= 8u;
+}
+
+// shape.rs:1212-1281 (Q8)
+DEV void isect_cone(const Ray &r, double minimum, double maximum, int closed, Recs &o) {
+    const double a = r.d.x * r.d.x - r.d.y * r.d.y + r.d.z * r.d.z;
+    const double b = 2. * r.o.x * r.d.x - 2. * r.o.y * r.d.y + 2. * r.o.z * r.d.z;
+    const double c = r.o.x * r.o.x - r.o.y * r.o.y + r.o.z * r.o.z;
+    if (approx_zero(a)) {
+        if (!closed) {
+            o.t0 = -c / (2. * b);  // no y-range check, no b != 0 check
+            o.mask = 1u;
+            return;
+        }
+    } else {
+        const double disc = b * b - 4. * a * c;
+        if (disc < 0.) return;
+        const double sq = sqrt(disc);
+        double t0 = (-b - sq) / (2. * a);
+        double t1 = (-b + sq) / (2. * a);
+        if (t0 > t1) {
+            const double t = t0;
+            t0 = t1;
+            t1 = t;
+        }
+        const double y0 = r.o.y + t0 * r.d.y;
+        if (minimum < y0 && y0 < maximum) o.t0 = t0, o.mask |= 1u;
+        const double y1 = r.o.y + t1 * r.d.y;
+        if (minimum < y1 && y1 < maximum) o.t1 = t1, o.mask |= 2u;
+    }
+    // intersect_caps, shape.rs:1260-1281: |min| / |max| for both the plane height and the radius
+    if (!closed || approx_zero(r.d.y)) return;
+    const double amin = fabs(minimum), amax = fabs(maximum);
+    double t = (amin - r.o.y) / r.d.y;
+    if (check_cap(r, t, amin)) o.t2 = t, o.mask |= 4u;
+    t = (amax - r.o.y) / r.d.y;
+    if (check_cap(r, t, amax)) o.t3 = t, o.mask |= 8u;
+}
+
+// shape.rs:1479-1502 == 1712-1735
+DEV void isect_triangle(const Ray &r, const DTri &tr, Recs &o) {
+    const V3 e1 = ld3(tr.e1), e2 = ld3(tr.e2), p1 = ld3(tr.p1);
+    const V3 dce2 = cross(r.d, e2);
+    const double det = dot(e1, dce2);
+    if (fabs(det) < RTC_EPS) return;
+    const double f = 1. / det;
+    const V3 p1o = r.o - p1;
+    const double u = f * dot(p1o, dce2);
+    if (!(0. <= u && u <= 1.)) return;
+    const V3 oce1 = cross(p1o, e1);
+    const double v = f * dot(r.d, oce1);
+    if (v < 0. || (u + v) > 1.) return;
+    o.t0 = f * dot(e2, oce1);
+    o.u = u, o.v = v;
+    o.mask = 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-lane state
+// ---------------------------------------------------------------------------------------------
+
+struct Counters {
+    unsigned long long c[ST_COUNT];
+};
+
+template <bool STATS>
+struct Ctx {
+    const DScene &s;
+    int *stack;  // LDS, this lane's column: stack[k * RTC_WAVE]
+    // lane-local cache of the last object-space ray (primitives of one mesh share their parent chain)
+    int cache_chain;
+    Ray cache_ray;  // reset whenever a new world ray starts (trace())
+    Counters *cnt;
+    DEV void count(int idx, unsigned long long n = 1) {
+        if (STATS) cnt->c[idx] += n;
+    }
+};
+
+// Ray::transform down the parent chain (shape.rs:2035, then the shape's own :256 etc.), root first.
+template <bool STATS>
+DEV Ray to_object(Ctx<STATS> &cx, const DPrim &p, const Ray &world) {
+    if (p.chain_len == 0) return world;
+    const bool shared_chain = p.type >= PT_TRIANGLE;  // only mesh triangles share a chain
+    if (shared_chain && p.chain_id == cx.cache_chain) return cx.cache_ray;
+    Ray r = world;
+    for (int k = 0; k < p.chain_len; k++) {
+        const double *m = cx.s.xforms[cx.s.chains[p.chain_off + k]].inv;
+        Ray q;
+        q.o = xf_point(m, r.o);
+        q.d = xf_vector(m, r.d);
+        r = q;
+    }
+    cx.count(ST_XFORM, (unsigned long long)p.chain_len);
+    if (shared_chain) {
+        cx.cache_chain = p.chain_id;
+        cx.cache_ray = r;
+    }
+    return r;
+}
+
+template <bool STATS>
+DEV void intersect_prim(Ctx<STATS> &cx, int pi, const Ray &world, Recs &rc) {
+    const DPrim &p = cx.s.prims[pi];
+    rc.mask = 0u;
+    const Ray r = to_object(cx, p, world);
+    cx.count(ST_PRIM0 + p.type);
+    switch (p.type) {
+    case PT_SPHERE: isect_sphere(r, rc); break;
+    case PT_PLANE: isect_plane(r, rc); break;
+    case PT_CUBE: isect_cube(r, rc); break;
+    case PT_CYLINDER: isect_cylinder(r, p.minimum, p.maximum, p.closed, rc); break;
+    case PT_CONE: isect_cone(r, p.minimum, p.maximum, p.closed, rc); break;
+    default: isect_triangle(r, cx.s.tris[p.tri], rc); break;
+    }
+    // records whose t is NaN can never be the hit (intersection.rs:211-214); they are dropped here
+    // (DESIGN.md "NaN records")
+    if ((rc.mask & 1u) && rc.t0 != rc.t0) rc.mask &= ~1u;
+    if ((rc.mask & 2u) && rc.t1 != rc.t1) rc.mask &= ~2u;
+    if ((rc.mask & 4u) && rc.t2 != rc.t2) rc.mask &= ~4u;
+    if ((rc.mask & 8u) && rc.t3 != rc.t3) rc.mask &= ~8u;
+}
+
+struct Hit {
+    double t;
+    int prim;
+    double u, v;
+};
+
+// hit() over this primitive's records (intersection.rs:207-219): smallest t > 0, first record wins on ties;
+// between primitives the lower flattened index wins (stable order, Q15).
+DEV void closest_visit(Hit &best, int pi, const Recs &rc) {
+#define RTC_TRY(bit, tt)                                                                      \
+    if ((rc.mask & (bit)) && (tt) > 0. && ((tt) < best.t || ((tt) == best.t && pi < best.prim))) { \
+        best.t = (tt);                                                                        \
+        best.prim = pi;                                                                       \
+        best.u = rc.u;                                                                        \
+        best.v = rc.v;                                                                        \
+    }
+    RTC_TRY(1u, rc.t0)
+    RTC_TRY(2u, rc.t1)
+    RTC_TRY(4u, rc.t2)
+    RTC_TRY(8u, rc.t3)
+#undef RTC_TRY
+}
+
+// Streaming form of the containers loop (intersection.rs:150-179).  For one primitive: count the records
+// strictly before the hit and remember the latest of them.  A primitive is "in containers" just before the
+// hit iff that count is odd, and the list's last element is the open primitive whose last record is latest
+// in the (stably) sorted order, i.e. max over (last_t, primitive index).
+struct Containers {
+    double t_hit;
+    int hit_prim;
+    double best_t;   // latest crossing among OTHER open primitives
+    int best_prim;   // -1: none
+    int hit_open;    // hit primitive has an odd number of records before the hit
+    double hit_last;
+};
+DEV void container_visit(Containers &c, int pi, const Recs &rc) {
+    int n = 0;
+    double last = 0.;
+#define RTC_CNT(bit, tt)                          \
+    if ((rc.mask & (bit)) && (tt) < c.t_hit) {    \
+        if (n == 0 || (tt) >= last) last = (tt);  \
+        n++;                                      \
+    }
+    RTC_CNT(1u, rc.t0)
+    RTC_CNT(2u, rc.t1)
+    RTC_CNT(4u, rc.t2)
+    RTC_CNT(8u, rc.t3)
+#undef RTC_CNT
+    if (!(n & 1)) return;
+    if (pi == c.hit_prim) {
+        c.hit_open = 1;
+        c.hit_last = last;
+    } else if (c.best_prim < 0 || last > c.best_t || (last == c.best_t && pi > c.best_prim)) {
+        c.best_t = last;
+        c.best_prim = pi;
+    }
+}
+
+// Slab test against a padded world-space box.  fmin/fmax drop NaNs (0 * inf on a boundary plane), which
+// keeps the test conservative.
+DEV bool box_interval(const DBvhNode &n, const V3 &o, const V3 &inv_d, double lo, double hi, double &tnear) {
+    double t1 = (n.bmin[0] - o.x) * inv_d.x, t2 = (n.bmax[0] - o.x) * inv_d.x;
+    double tn = fmin(t1, t2), tf = fmax(t1, t2);
+    t1 = (n.bmin[1] - o.y) * inv_d.y, t2 = (n.bmax[1] - o.y) * inv_d.y;
+    tn = fmax(tn, fmin(t1, t2)), tf = fmin(tf, fmax(t1, t2));
+    t1 = (n.bmin[2] - o.z) * inv_d.z, t2 = (n.bmax[2] - o.z) * inv_d.z;
+    tn = fmax(tn, fmin(t1, t2)), tf = fmin(tf, fmax(t1, t2));
+    tnear = tn;
+    return tn <= tf && tn <= hi && tf >= lo;
+}
+
+enum TraceMode { TM_CLOSEST = 0, TM_ANY = 1, TM_CONTAINER = 2 };
+
+// World::intersect (world.rs:176-186) without materialising the list.
+//   TM_CLOSEST: nearest record with 0 < t < best.t (best.t preset to the search bound)
+//   TM_ANY:     stop at the first record with 0 < t < best.t
+//   TM_CONTAINER: visit every primitive with a record t < cont.t_hit
+template <int MODE, bool STATS>
+DEV void trace(Ctx<STATS> &cx, const Ray &ray, bool use_bvh, Hit &best, Containers &cont) {
+    const DScene &s = cx.s;
+    cx.cache_chain = -1;
+    Recs rc;
+    rc.t0 = rc.t1 = rc.t2 = rc.t3 = 0.;
+    rc.u = rc.v = 0.;
+    const int n_linear = use_bvh ? s.n_unbounded : s.n_prims;
+    for (int i = 0; i < n_linear; i++) {
+        const int pi = use_bvh ? s.unbounded[i] : i;
+        intersect_prim(cx, pi, ray, rc);
+        if (MODE == TM_CONTAINER) {
+            container_visit(cont, pi, rc);
+        } else {
+            closest_visit(best, pi, rc);
+            if (MODE == TM_ANY && best.prim >= 0) return;
+        }
+    }
+    if (!use_bvh || s.n_bvh_nodes == 0) return;
+
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    const V3 inv_d = mk(1. / ray.d.x, 1. / ray.d.y, 1. / ray.d.z);
+    const double lo = (MODE == TM_CONTAINER) ? -inf : 0.;
+    int sp = 0;
+    int node = 0;
+    {
+        double tn;
+        cx.count(ST_BOX);
+        if (!box_interval(s.bvh[0], ray.o, inv_d, lo, (MODE == TM_CONTAINER) ? cont.t_hit : best.t, tn)) return;
+    }
+    for (;;) {
+        const DBvhNode &n = s.bvh[node];
+        const int count = n.count, left = n.left;
+        bool pop = true;
+        if (count > 0) {
+            for (int k = 0; k < count; k++) {
+                const int pi = s.bvh_prims[left + k];
+                intersect_prim(cx, pi, ray, rc);
+                if (MODE == TM_CONTAINER) {
+                    container_visit(cont, pi, rc);
+                } else {
+                    closest_visit(best, pi, rc);
+                    if (MODE == TM_ANY && best.prim >= 0) return;
+                }
+            }
+        } else {
+            const double hi = (MODE == TM_CONTAINER) ? cont.t_hit : best.t;
+            double tl, tr;
+            cx.count(ST_BOX, 2);
+            const bool hl = box_interval(s.bvh[left], ray.o, inv_d, lo, hi, tl);
+            const bool hr = box_interval(s.bvh[left + 1], ray.o, inv_d, lo, hi, tr);
+            if (hl && hr) {
+                const bool left_first = (MODE == TM_CONTAINER) ? true : (tl <= tr);
+                const int far = left_first ? left + 1 : left;
+                node = left_first ? left : left + 1;
+                if (sp < RTC_BVH_STACK) cx.stack[sp * RTC_WAVE] = far, sp++;
+                pop = false;
+            } else if (hl || hr) {
+                node = hl ? left : left + 1;
+                pop = false;
+            }
+        }
+        if (pop) {
+            // pop until a node that can still matter
+            for (;;) {
+                if (sp == 0) return;
+                sp--;
+                node = cx.stack[sp * RTC_WAVE];
+                if (MODE == TM_CONTAINER) break;
+                double tn;
+                cx.count(ST_BOX);
+                if (box_interval(s.bvh[node], ray.o, inv_d, lo, best.t, tn)) break;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shading
+// ---------------------------------------------------------------------------------------------
+
+// Shape::normal_at (shape.rs:43-47): world_to_object down the chain (shape.rs:82-90), local normal,
+// normal_to_world back up with a normalisation per level (shape.rs:94-103).
+template <bool STATS>
+DEV V3 normal_at(Ctx<STATS> &cx, const DPrim &p, V3 world_point, double hu, double hv) {
+    const DScene &s = cx.s;
+    V3 n;
+    if (p.type >= PT_TRIANGLE) {
+        const DTri &tr = s.tris[p.tri];
+        if (p.type == PT_TRIANGLE) {
+            n = ld3(tr.n1);  // shape.rs:1516-1518
+        } else {             // shape.rs:1749-1754
+            n = ld3(tr.n2) * hu + ld3(tr.n3) * hv + ld3(tr.n1) * (1. - hu - hv);
+        }
+        // the triangle's own transformation() is the identity (shape.rs:1550-1552): only the normalisation
+        // of that level remains
+        n = normalize(n);
+    } else {
+        V3 lp = world_point;
+        for (int k = 0; k < p.chain_len; k++) lp = xf_point(s.xforms[s.chains[p.chain_off + k]].inv, lp);
+        switch (p.type) {
+        case PT_SPHERE: n = lp - mk(0., 0., 0.); break;  // shape.rs:273-279
+        case PT_PLANE: n = mk(0., 1., 0.); break;         // shape.rs:550-553
+        case PT_CUBE: {                                   // shape.rs:743-757
+            const double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
+            const double mc = max3_total(ax, ay, az);
+            if (mc == ax)
+                n = mk(lp.x, 0., 0.);
+            else if (mc == ay)
+                n = mk(0., lp.y, 0.);
+            else
+                n = mk(0., 0., lp.z);
+            break;
+        }
+        case PT_CYLINDER: {  // shape.rs:983-998
+            const double dist = lp.x * lp.x + lp.z * lp.z;
+            if (dist < 1. && lp.y >= p.maximum - RTC_EPS)
+                n = mk(0., 1., 0.);
+            else if (dist < 1. && lp.y <= p.minimum + RTC_EPS)
+                n = mk(0., -1., 0.);
+            else
+                n = mk(lp.x, 0., lp.z);
+            break;
+        }
+        default: {  // PT_CONE, shape.rs:1302-1314
+            const double dist = lp.x * lp.x + lp.z * lp.z;
+            if (dist < 1. && lp.y >= p.maximum - RTC_EPS)
+                n = mk(0., 1., 0.);
+            else if (dist < 1. && lp.y <= p.minimum + RTC_EPS)
+                n = mk(0., -1., 0.);
+            else {
+                double y = sqrt(lp.x * lp.x + lp.z * lp.z);
+                y = (lp.y > 0.) ? -y : y;
+                n = mk(lp.x, y, lp.z);
+            }
+            break;
+        }
+        }
+        // own level
+        n = normalize(xf_normal(s.xforms[s.chains[p.chain_off + p.chain_len - 1]].inv, n));
+    }
+    // ancestors, innermost first
+    const int first_parent = (p.type >= PT_TRIANGLE) ? p.chain_len - 1 : p.chain_len - 2;
+    for (int k = first_parent; k >= 0; k--) n = normalize(xf_normal(s.xforms[s.chains[p.chain_off + k]].inv, n));
+    return n;
+}
+
+// Rust's `%` on f64 is fmod; pattern.rs kinds
+DEV V3 pattern_eval(const DScene &s, int pi, V3 p) {
+    // Stripe / Checker select a sub-pattern and evaluate it at the same point (pattern.rs:114-121, 380-386);
+    // Blended needs both children (pattern.rs:584-591) -> small explicit stack with halving weights.
+    V3 acc = mk(0., 0., 0.);
+    int st_pat[RTC_MAX_DEPTH_STACK];
+    double st_w[RTC_MAX_DEPTH_STACK];
+    int sp = 0;
+    double w = 1.;
+    bool weighted = false;
+    for (;;) {
+        const DPattern &pt = s.patterns[pi];
+        V3 c;
+        bool leaf = true;
+        switch (pt.kind) {
+        case RTC_PAT_STRIPE:
+            pi = (fmod(floor(p.x), 2.) == 0.) ? pt.sub_a : pt.sub_b;
+            leaf = false;
+            break;
+        case RTC_PAT_CHECKER:
+            pi = (fmod(floor(p.x) + floor(p.y) + floor(p.z), 2.) == 0.) ? pt.sub_a : pt.sub_b;
+            leaf = false;
+            break;
+        case RTC_PAT_BLENDED:
+            weighted = true;
+            w = w / 2.;
+            if (sp < RTC_MAX_DEPTH_STACK) st_pat[sp] = pt.sub_b, st_w[sp] = w, sp++;
+            pi = pt.sub_a;
+            leaf = false;
+            break;
+        case RTC_PAT_GRADIENT: {  // pattern.rs:228-231
+            const V3 d = ld3(pt.b) - ld3(pt.a);
+            c = ld3(pt.a) + d * p.x;
+            break;
+        }
+        case RTC_PAT_RING:  // pattern.rs:297-303
+            c = (fmod(floor(sqrt(p.x * p.x + p.z * p.z)), 2.) == 0.) ? ld3(pt.a) : ld3(pt.b);
+            break;
+        case RTC_PAT_RADIAL: {  // pattern.rs:472-476
+            const double dist = sqrt(p.x * p.x + p.z * p.z);
+            const double frac = dist - floor(dist);
+            c = ld3(pt.a) + (ld3(pt.b) - ld3(pt.a)) * frac;
+            break;
+        }
+        case RTC_PAT_SOLID: c = ld3(pt.a); break;  // pattern.rs:533-535
+        default: c = p; break;                     // RTC_PAT_TEST, pattern.rs:669-671
+        }
+        if (!leaf) continue;
+        if (!weighted) return c;
+        acc = acc + c * w;
+        if (sp == 0) return acc;
+        sp--;
+        pi = st_pat[sp];
+        w = st_w[sp];
+    }
+}
+
+// Pattern::pattern_at_shape (pattern.rs:25-32; Q13: only the shape's own transform; Solid override :538-540)
+DEV V3 pattern_at_shape(const DScene &s, int pat, const DPrim &p, V3 world_point) {
+    const DPattern &pt = s.patterns[pat];
+    if (pt.kind == RTC_PAT_SOLID) return ld3(pt.a);
+    V3 op = world_point;
+    if (p.own_xform >= 0) op = xf_point(s.xforms[p.own_xform].inv, op);
+    const V3 pp = xf_point(pt.inv, op);
+    return pattern_eval(s, pat, pp);
+}
+
+// Material::lighting, material.rs:20-75
+DEV V3 lighting(const DMaterial &m, V3 color, V3 light_pos, V3 light_int, V3 point, V3 eye, V3 normal,
+                double intensity) {
+    const V3 effective = cmul(color, light_int);
+    const V3 lightv = normalize(light_pos - point);
+    const V3 ambient = effective * m.ambient;
+    const double ldn = dot(lightv, normal);
+    V3 diffuse = mk(0., 0., 0.), specular = mk(0., 0., 0.);
+    if (!(ldn < 0.)) {
+        diffuse = effective * m.diffuse * ldn * intensity;
+        const V3 rv = reflect(-lightv, normal);
+        const double rde = dot(rv, eye);
+        if (rde <= 0.) {
+            specular = mk(0., 0., 0.) * intensity;
+        } else {
+            const double factor = pow(rde, m.shininess);
+            specular = light_int * m.specular * factor * intensity;
+        }
+    }
+    return ambient + specular + diffuse;
+}
+
+// Computations::schlick, intersection.rs:66-90
+DEV double schlick(double n1, double n2, V3 eye, V3 normal) {
+    double c = dot(eye, normal);
+    if (n1 > n2) {
+        const double n = n1 / n2;
+        const double sin2_t = (n * n) * (1. - c * c);
+        if (sin2_t > 1.) return 1.;
+        c = sqrt(1. - sin2_t);
+    }
+    const double q = (n1 - n2) / (n1 + n2);
+    const double r0 = q * q;
+    const double x = 1. - c;
+    const double x2 = x * x;
+    return r0 + (1. - r0) * (x * (x2 * x2));  // powi(5)
+}
+
+struct Pending {
+    V3 o, d;
+    double w, mult;
+    int remaining;
+};
+
+// World::is_shadowed (world.rs:78-91): only the NEAREST positive hit is consulted (Q5).  When every material
+// casts shadows, "nearest hit has t < distance" is equivalent to "some hit has 0 < t < distance".
+template <bool STATS>
+DEV bool is_shadowed(Ctx<STATS> &cx, V3 point, V3 light_pos, bool use_bvh) {
+    const V3 dv = light_pos - point;
+    const double distance = magnitude(dv);
+    Ray r;
+    r.o = point;
+    r.d = normalize(dv);
+    Hit h;
+    h.t = distance, h.prim = -1, h.u = h.v = 0.;
+    Containers dummy;
+    cx.count(ST_SHADOW);
+    if (cx.s.all_cast_shadow) {
+        trace<TM_ANY, STATS>(cx, r, use_bvh, h, dummy);
+        return h.prim >= 0;
+    }
+    trace<TM_CLOSEST, STATS>(cx, r, use_bvh, h, dummy);
+    return h.prim >= 0 && cx.s.materials[cx.s.prims[h.prim].material].casts_shadow != 0;
+}
+
+// Light::intensity_at: PointLight light.rs:50-56, AreaLight light.rs:112-125
+template <bool STATS>
+DEV double intensity_at(Ctx<STATS> &cx, const DLight &l, V3 point, bool use_bvh) {
+    if (!l.is_area) return is_shadowed(cx, point, ld3(l.position), use_bvh) ? 0. : 1.;
+    double total = 0.;
+    for (unsigned v = 0; v < l.vsteps; v++)
+        for (unsigned u = 0; u < l.usteps; u++) {
+            // light.rs:106-108
+            const V3 lp = ld3(l.corner) + ld3(l.uvec) * ((double)u + 0.5) + ld3(l.vvec) * ((double)v + 0.5);
+            if (!is_shadowed(cx, point, lp, use_bvh)) total += 1.;
+        }
+    return total / (double)l.samples;
+}
+
+// canvas row of this rank's local row l (interleaved row tiles)
+DEV unsigned canvas_row(const DRenderParams &p, unsigned l) {
+    if (p.tile_count <= 1) return l;
+    const unsigned k = l / p.tile_rows;
+    return (k * p.tile_count + p.tile_index) * p.tile_rows + (l - k * p.tile_rows);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(RTC_WAVE) void k_render(DScene s, DRenderParams prm, double *__restrict__ out,
+                                                      unsigned long long *__restrict__ stats) {
+    __shared__ int bvh_stack[RTC_BVH_STACK * RTC_WAVE];
+    const unsigned lane = threadIdx.x;
+    const unsigned tile = blockIdx.x;
+    const unsigned tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
+    const unsigned x = tx * 8u + (lane & 7u);
+    const unsigned l = ty * 8u + (lane >> 3);
+    const bool in_image = x < s.cam.hsize && l < prm.local_rows;
+    const unsigned y = canvas_row(prm, l);
+    // camera.rs:72,78: rows 0..vsize-1 and columns 0..hsize-1 (exclusive) -- Q1
+    const bool active = in_image && (x + 1u < s.cam.hsize) && (y + 1u < s.cam.vsize);
+    const bool use_bvh = prm.use_bvh != 0;
+
+    Counters cnt;
+    if (STATS)
+        for (int i = 0; i < ST_COUNT; i++) cnt.c[i] = 0;
+    Ctx<STATS> cx{s, &bvh_stack[lane], -1, Ray{}, &cnt};
+
+    V3 color = mk(0., 0., 0.);
+    if (active) {
+        // Camera::ray_for_pixel, camera.rs:41-59
+        Ray ray;
+        {
+            const double xo = ((double)x + 0.5) * s.cam.pixel_size;
+            const double yo = ((double)y + 0.5) * s.cam.pixel_size;
+            const double wx = s.cam.half_width - xo;
+            const double wy = s.cam.half_height - yo;
+            const V3 pixel = xf_point(s.cam.inv, mk(wx, wy, -1.));
+            ray.o = xf_point(s.cam.inv, mk(0., 0., 0.));
+            ray.d = normalize(pixel - ray.o);
+        }
+        cx.count(ST_PRIMARY);
+        const double inf = __longlong_as_double(0x7ff0000000000000LL);
+        double w = 1., mult = 1.;
+        int remaining = (int)prm.depth;
+        Pending pend[RTC_MAX_DEPTH_STACK];
+        int sp = 0;
+        int rays = 0;
+        const double nl = (double)s.n_lights;
+        for (;;) {
+            if (++rays > RTC_MAX_RAYS_PER_PIXEL) {
+                cx.count(ST_OVERFLOW);
+                if (!STATS) color = mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.);
+                break;
+            }
+            // World::color_at, world.rs:30-38
+            Hit h;
+            h.t = inf, h.prim = -1, h.u = h.v = 0.;
+            Containers cont;
+            trace<TM_CLOSEST, STATS>(cx, ray, use_bvh, h, cont);
+            bool follow = false;
+            if (h.prim >= 0 && s.n_lights > 0) {
+                const DPrim &p = s.prims[h.prim];
+                const DMaterial &m = s.materials[p.material];
+                // Intersection::prepare_computations, intersection.rs:123-148
+                const V3 point = ray.o + ray.d * h.t;
+                const V3 eye = -ray.d;
+                V3 normal = normal_at(cx, p, point, h.u, h.v);
+                if (dot(normal, eye) < 0.) normal = -normal;
+                const V3 reflectv = reflect(ray.d, normal);
+                const V3 over = point + normal * RTC_EPS;
+                const V3 under = point - normal * RTC_EPS;
+                cx.count(ST_SHADED);
+
+                // World::shade_hit, world.rs:42-76 -- surface terms, left fold over the lights
+                V3 surface = mk(0., 0., 0.);
+                const V3 base = ld3(m.color);
+                for (int li = 0; li < s.n_lights; li++) {
+                    const DLight &lt = s.lights[li];
+                    const double inten = intensity_at(cx, lt, over, use_bvh);
+                    const V3 col = (m.pattern >= 0) ? pattern_at_shape(s, m.pattern, p, over) : base;
+                    const V3 c = lighting(m, col, ld3(lt.position), ld3(lt.intensity), over, eye, normal, inten);
+                    cx.count(ST_LIGHT);
+                    surface = (li == 0) ? c : surface + c;
+                }
+                color = color + surface * w;
+
+                // reflected_color / refracted_color, world.rs:93-147.  The reference evaluates both inside the
+                // per-light loop (Q3), i.e. adds them n_lights times: the factor goes into the child's weight.
+                if (remaining > 0) {
+                    const bool refl = m.reflectivity != 0.;
+                    const bool refr = m.transparency != 0.;
+                    double kr = 1., kt = 1.;
+                    double n1 = 1., n2 = 1.;
+                    if (refr) {
+                        // containers loop in streaming form
+                        cont.t_hit = h.t, cont.hit_prim = h.prim;
+                        cont.best_t = 0., cont.best_prim = -1, cont.hit_open = 0, cont.hit_last = 0.;
+                        Hit unused;
+                        unused.t = inf, unused.prim = -1, unused.u = unused.v = 0.;
+                        cx.count(ST_CONTAINER);
+                        trace<TM_CONTAINER, STATS>(cx, ray, use_bvh, unused, cont);
+                        const double ri_hit = m.refractive_index;
+                        const double ri_other =
+                            (cont.best_prim >= 0) ? s.materials[s.prims[cont.best_prim].material].refractive_index : 1.;
+                        if (cont.hit_open) {
+                            // the hit primitive leaves: n1 = last of (others + hit), n2 = last of others
+                            const bool hit_is_last =
+                                cont.best_prim < 0 || cont.hit_last > cont.best_t ||
+                                (cont.hit_last == cont.best_t && h.prim > cont.best_prim);
+                            n1 = hit_is_last ? ri_hit : ri_other;
+                            n2 = ri_other;
+                        } else {
+                            // the hit primitive enters and becomes the last container
+                            n1 = ri_other;
+                            n2 = ri_hit;
+                        }
+                    }
+                    if (m.reflectivity > 0. && m.transparency > 0.) {
+                        const double r = schlick(n1, n2, eye, normal);
+                        cx.count(ST_SCHLICK);
+                        kr = r;
+                        kt = 1. - r;
+                    }
+                    if (refr) {
+                        // world.rs:116-142
+                        const double n_ratio = n1 / n2;
+                        const double cos_i = dot(eye, normal);
+                        const double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+                        cx.count(ST_REFRACT);
+                        if (!(sin2_t > 1.)) {
+                            const double cos_t = sqrt(1. - sin2_t);
+                            Pending q;
+                            q.o = under;
+                            q.d = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
+                            q.w = w * (nl * (m.transparency * kt));
+                            q.mult = mult * nl;
+                            q.remaining = remaining;  // Q2: not decremented (world.rs:142)
+                            if (sp < RTC_MAX_DEPTH_STACK) {
+                                pend[sp] = q;
+                                sp++;
+                            } else {
+                                cx.count(ST_OVERFLOW);
+                            }
+                        }
+                    }
+                    if (refl) {
+                        // world.rs:103-105
+                        ray.o = over;
+                        ray.d = reflectv;
+                        w = w * (nl * (m.reflectivity * kr));
+                        mult = mult * nl;
+                        remaining -= 1;
+                        follow = true;
+                    }
+                }
+            }
+            if (!follow) {
+                if (sp == 0) break;
+                sp--;
+                const Pending q = pend[sp];
+                ray.o = q.o, ray.d = q.d, w = q.w, mult = q.mult, remaining = q.remaining;
+            }
+            cx.count(ST_SECONDARY);
+            if (STATS) cnt.c[ST_SECONDARY_REF] += (unsigned long long)mult;
+        }
+    }
+    if (in_image) {
+        double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
+        px[0] = color.x, px[1] = color.y, px[2] = color.z;
+    }
+    if (STATS) {
+        for (int i = 0; i < ST_COUNT; i++) {
+            unsigned long long v = cnt.c[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, RTC_WAVE);
+            if (lane == 0 && v) atomicAdd(&stats[i], v);
+        }
+    }
+}
+
+int launch_render(const DScene &scene, const DRenderParams &params, double *d_rgb, uint64_t *d_stats,
+                  bool collect_stats, void *stream) {
+    const unsigned tiles = params.tiles_x * params.tiles_y;
+    if (tiles == 0) return RTC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (collect_stats)
+        hipLaunchKernelGGL(k_render<true>, dim3(tiles), dim3(RTC_WAVE), 0, st, scene, params, d_rgb,
+                           (unsigned long long *)d_stats);
+    else
+        hipLaunchKernelGGL(k_render<false>, dim3(tiles), dim3(RTC_WAVE), 0, st, scene, params, d_rgb,
+                           (unsigned long long *)d_stats);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("kernel launch failed: %s", hipGetErrorString(e));
+        return RTC_ERR_HIP;
+    }
+    return RTC_OK;
+}
+
+}  // namespace rtc

@@ -1,0 +1,629 @@
+// rtc_scene.cpp -- flattening of the Shape tree into SoA device tables, host BVH, upload.
+//
+// The reference keeps shapes as Arc<dyn Shape> trees with a global parent registry
+// (ray_tracer/src/shape.rs:22-24, 82-103, 1930-1942).  On the device there is no tree: every leaf shape
+// becomes one DPrim in depth-first order (the order World::intersect / Group::local_intersect visit them,
+// world.rs:176-186, shape.rs:1930-1942) and carries the root-first list of inverse transforms the reference
+// would apply one after another (shape.rs:2035 then e.g. :256; shape.rs:82-103 for points and normals).
+#include "rtc_scene.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <limits>
+
+namespace rtc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char *last_error() { return g_err; }
+
+Scene::~Scene() { release_device(); }
+
+void Scene::release_device() {
+    if (device >= 0 && (!device_allocs.empty() || ev_start)) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(device);
+        for (void *p : device_allocs) (void)hipFree(p);
+        if (ev_start) (void)hipEventDestroy((hipEvent_t)ev_start);
+        if (ev_stop) (void)hipEventDestroy((hipEvent_t)ev_stop);
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    device_allocs.clear();
+    ev_start = ev_stop = nullptr;
+    d_stats = nullptr;
+    device_bytes = 0;
+}
+
+int Scene::add_item(Item &&it) {
+    it.parent = open_groups.empty() ? -1 : open_groups.back();
+    const int idx = (int)items.size();
+    items.push_back(std::move(it));
+    if (items[idx].parent >= 0)
+        items[items[idx].parent].children.push_back(idx);
+    else
+        top_level.push_back(idx);
+    return idx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// flatten
+// ---------------------------------------------------------------------------------------------
+
+static void store_inv(const Mat4 &inv, double out[12]) {
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) out[r * 4 + c] = inv.m[r][c];
+}
+
+static const double INF = std::numeric_limits<double>::infinity();
+
+// Object-space bounds of an analytic shape; false = unbounded (goes to the always-tested list).
+static bool local_bounds(const Item &it, Bounds &b) {
+    switch (it.type) {
+    case RTC_SPHERE:
+    case RTC_CUBE:
+        for (int a = 0; a < 3; a++) b.lo[a] = -1.0, b.hi[a] = 1.0;
+        return true;
+    case RTC_PLANE: return false;
+    case RTC_CYLINDER:
+        // side hits: y in (min, max), x^2+z^2 = 1; caps at y = min / max with x^2+z^2 <= 1 (shape.rs:895-959)
+        if (!std::isfinite(it.minimum) || !std::isfinite(it.maximum)) return false;
+        b.lo[0] = b.lo[2] = -1.0, b.hi[0] = b.hi[2] = 1.0;
+        b.lo[1] = std::min(it.minimum, it.maximum), b.hi[1] = std::max(it.minimum, it.maximum);
+        return true;
+    case RTC_CONE: {
+        // An OPEN cone returns an unclipped hit when |a| < EPSILON (shape.rs:1219-1225, Q8), so it can be hit
+        // anywhere along the infinite double cone: never bounded.  A CLOSED cone yields side hits with
+        // y in (min, max) (radius |y|) and cap hits on the planes y = |min|, y = |max| with
+        // x^2 + z^2 <= |limit| (NOT squared, shape.rs:1269-1277 + intersection.rs:34-39).
+        if (!it.closed) return false;
+        if (!std::isfinite(it.minimum) || !std::isfinite(it.maximum)) return false;
+        const double amin = std::fabs(it.minimum), amax = std::fabs(it.maximum);
+        const double r = std::max(std::max(amin, amax), std::max(std::sqrt(amin), std::sqrt(amax)));
+        b.lo[0] = b.lo[2] = -r, b.hi[0] = b.hi[2] = r;
+        b.lo[1] = std::min(std::min(it.minimum, it.maximum), std::min(amin, amax));
+        b.hi[1] = std::max(std::max(it.minimum, it.maximum), std::max(amin, amax));
+        return true;
+    }
+    default: return false;
+    }
+}
+
+static void bounds_empty(Bounds &b) {
+    for (int a = 0; a < 3; a++) b.lo[a] = INF, b.hi[a] = -INF;
+}
+static void bounds_add(Bounds &b, Vec3 p) {
+    const double v[3] = {p.x, p.y, p.z};
+    for (int a = 0; a < 3; a++) {
+        b.lo[a] = std::min(b.lo[a], v[a]);
+        b.hi[a] = std::max(b.hi[a], v[a]);
+    }
+}
+// Conservative padding: the BVH must never cull a hit the reference's own (rounded) arithmetic would
+// report.  1e-6 relative to the largest coordinate / extent dwarfs every f64 rounding error on the path
+// (1e-16 relative) and costs nothing measurable in traversal.
+static void bounds_pad(Bounds &b) {
+    double scale = 0.0;
+    for (int a = 0; a < 3; a++)
+        scale = std::max(scale, std::max(std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])), b.hi[a] - b.lo[a]));
+    const double pad = 1e-6 * scale + 1e-9;
+    for (int a = 0; a < 3; a++) b.lo[a] -= pad, b.hi[a] += pad;
+}
+
+int Scene::flatten() {
+    xforms.clear(), xform_fwd.clear(), chains.clear(), prims.clear(), tris.clear();
+    prim_bounds.clear(), prim_bounded.clear(), unbounded.clear(), bvh.clear(), bvh_prims.clear();
+    dmaterials.clear(), dpatterns.clear();
+
+    if (!has_camera) {
+        set_error("scene has no camera (parse_scene ParseError::MissingCamera)");
+        return RTC_ERR_INVALID;
+    }
+    // camera.rs:17-37
+    {
+        Mat4 inv;
+        if (!mat_inverse(view, inv)) {
+            set_error("camera transformation is not invertible");
+            return RTC_ERR_NON_INVERTIBLE;
+        }
+        store_inv(inv, cam.inv);
+        const double half_view = std::tan(fov / 2.);
+        const double aspect = (double)hsize / (double)vsize;
+        if (aspect >= 1.) {
+            cam.half_width = half_view;
+            cam.half_height = half_view / aspect;
+        } else {
+            cam.half_width = half_view * aspect;
+            cam.half_height = half_view;
+        }
+        cam.pixel_size = cam.half_width * 2. / (double)hsize;
+        cam.hsize = hsize;
+        cam.vsize = vsize;
+    }
+
+    for (const rtc_material &m : materials) {
+        DMaterial d;
+        for (int i = 0; i < 3; i++) d.color[i] = m.color[i];
+        d.ambient = m.ambient, d.diffuse = m.diffuse, d.specular = m.specular, d.shininess = m.shininess;
+        d.reflectivity = m.reflectivity, d.transparency = m.transparency, d.refractive_index = m.refractive_index;
+        d.casts_shadow = m.casts_shadow ? 1 : 0;
+        d.pattern = m.pattern;
+        if (m.pattern >= (int32_t)patterns.size()) {
+            set_error("material references pattern %d, only %zu defined", m.pattern, patterns.size());
+            return RTC_ERR_INVALID;
+        }
+        dmaterials.push_back(d);
+    }
+    for (const HostPattern &p : patterns) {
+        DPattern d{};
+        d.kind = p.kind, d.sub_a = p.sub_a, d.sub_b = p.sub_b;
+        for (int i = 0; i < 3; i++) d.a[i] = p.a[i], d.b[i] = p.b[i];
+        Mat4 inv;
+        if (!mat_inverse(p.transform, inv)) {
+            set_error("pattern transformation is not invertible");
+            return RTC_ERR_NON_INVERTIBLE;
+        }
+        store_inv(inv, d.inv);
+        dpatterns.push_back(d);
+    }
+
+    // Depth-first walk in insertion order.  chain_of[item] = (offset, len) of the root-first xform chain that
+    // applies to the CHILDREN of a group item.
+    struct Frame {
+        int item;
+        int32_t chain_off, chain_len;  // chain of the parent (applies to this item before its own transform)
+        int32_t group_material;        // material of the enclosing group or -1
+        int32_t chain_id;
+    };
+    std::vector<Frame> stack;
+    for (auto it = top_level.rbegin(); it != top_level.rend(); ++it) stack.push_back({*it, 0, 0, -1, -1});
+    int32_t next_chain_id = 0;
+    const int32_t root_chain_id = next_chain_id++;
+
+    auto push_xform = [&](const Mat4 &t, int32_t &idx) -> bool {
+        Mat4 inv;
+        if (!mat_inverse(t, inv)) return false;
+        DXform x;
+        store_inv(inv, x.inv);
+        idx = (int32_t)xforms.size();
+        xforms.push_back(x);
+        xform_fwd.push_back(t);
+        return true;
+    };
+    auto world_bounds = [&](const Bounds &local, int32_t chain_off, int32_t chain_len, Bounds &out) {
+        bounds_empty(out);
+        for (int corner = 0; corner < 8; corner++) {
+            Vec3 p = {(corner & 1) ? local.hi[0] : local.lo[0], (corner & 2) ? local.hi[1] : local.lo[1],
+                      (corner & 4) ? local.hi[2] : local.lo[2]};
+            for (int k = chain_len - 1; k >= 0; k--) p = mat_point(xform_fwd[chains[chain_off + k]], p);
+            bounds_add(out, p);
+        }
+        bounds_pad(out);
+    };
+
+    while (!stack.empty()) {
+        const Frame f = stack.back();
+        stack.pop_back();
+        const Item &it = items[f.item];
+        if (it.material >= (int32_t)materials.size()) {
+            set_error("shape references material %d, only %zu defined", it.material, materials.size());
+            return RTC_ERR_INVALID;
+        }
+        if (it.kind == Item::GROUP) {
+            int32_t xi;
+            if (!push_xform(it.transform, xi)) {
+                set_error("group transformation is not invertible");
+                return RTC_ERR_NON_INVERTIBLE;
+            }
+            const int32_t off = (int32_t)chains.size();
+            for (int k = 0; k < f.chain_len; k++) chains.push_back(chains[f.chain_off + k]);
+            chains.push_back(xi);
+            const int32_t cid = next_chain_id++;
+            for (auto c = it.children.rbegin(); c != it.children.rend(); ++c)
+                stack.push_back({*c, off, f.chain_len + 1, it.material, cid});
+        } else if (it.kind == Item::SHAPE) {
+            if (it.material < 0) {
+                set_error("shape without a material");
+                return RTC_ERR_INVALID;
+            }
+            int32_t xi;
+            if (!push_xform(it.transform, xi)) {
+                set_error("shape transformation is not invertible");
+                return RTC_ERR_NON_INVERTIBLE;
+            }
+            const int32_t off = (int32_t)chains.size();
+            for (int k = 0; k < f.chain_len; k++) chains.push_back(chains[f.chain_off + k]);
+            chains.push_back(xi);
+            DPrim p{};
+            p.type = it.type;  // rtc_shape_type values coincide with PrimType for the analytic shapes
+            p.material = it.material;
+            p.chain_off = off;
+            p.chain_len = f.chain_len + 1;
+            p.minimum = (it.type == RTC_CYLINDER || it.type == RTC_CONE) ? it.minimum : -INF;
+            p.maximum = (it.type == RTC_CYLINDER || it.type == RTC_CONE) ? it.maximum : INF;
+            p.closed = (it.type == RTC_CYLINDER || it.type == RTC_CONE) ? it.closed : 0;
+            p.tri = -1;
+            p.own_xform = xi;
+            p.chain_id = next_chain_id++;
+            Bounds lb, wb;
+            bounds_empty(wb);
+            const bool bounded = local_bounds(it, lb);
+            if (bounded) world_bounds(lb, p.chain_off, p.chain_len, wb);
+            prims.push_back(p);
+            prim_bounds.push_back(wb);
+            prim_bounded.push_back(bounded ? 1 : 0);
+        } else {
+            const size_t n = it.points.size() / 9;
+            const bool smooth = !it.normals.empty();
+            // shape.rs:1520-1532 / 1756-1768: the parent group's material wins when it is Some(..)
+            const int32_t mat = (f.group_material >= 0) ? f.group_material : it.material;
+            if (mat < 0) {
+                set_error("triangles without a material");
+                return RTC_ERR_INVALID;
+            }
+            for (size_t t = 0; t < n; t++) {
+                const double *q = &it.points[t * 9];
+                DTri d{};
+                const Vec3 p1 = {q[0], q[1], q[2]}, p2 = {q[3], q[4], q[5]}, p3 = {q[6], q[7], q[8]};
+                const Vec3 e1 = p2 - p1, e2 = p3 - p1;  // shape.rs:1463-1464
+                d.p1[0] = p1.x, d.p1[1] = p1.y, d.p1[2] = p1.z;
+                d.e1[0] = e1.x, d.e1[1] = e1.y, d.e1[2] = e1.z;
+                d.e2[0] = e2.x, d.e2[1] = e2.y, d.e2[2] = e2.z;
+                if (smooth) {
+                    const double *nn = &it.normals[t * 9];
+                    for (int i = 0; i < 3; i++) d.n1[i] = nn[i], d.n2[i] = nn[3 + i], d.n3[i] = nn[6 + i];
+                } else {
+                    const Vec3 nrm = vnorm(vcross(e2, e1));  // shape.rs:1465
+                    d.n1[0] = nrm.x, d.n1[1] = nrm.y, d.n1[2] = nrm.z;
+                }
+                DPrim p{};
+                p.type = smooth ? PT_SMOOTH_TRIANGLE : PT_TRIANGLE;
+                p.material = mat;
+                p.chain_off = f.chain_off;
+                p.chain_len = f.chain_len;
+                p.minimum = -INF, p.maximum = INF, p.closed = 0;
+                p.tri = (int32_t)tris.size();
+                p.own_xform = -1;
+                p.chain_id = (f.chain_id >= 0) ? f.chain_id : root_chain_id;
+                tris.push_back(d);
+                Bounds wb;
+                bounds_empty(wb);
+                const Vec3 vs[3] = {p1, p2, p3};
+                for (Vec3 v : vs) {
+                    for (int k = f.chain_len - 1; k >= 0; k--) v = mat_point(xform_fwd[chains[f.chain_off + k]], v);
+                    bounds_add(wb, v);
+                }
+                bounds_pad(wb);
+                bool finite = true;
+                for (int a = 0; a < 3; a++) finite = finite && std::isfinite(wb.lo[a]) && std::isfinite(wb.hi[a]);
+                prims.push_back(p);
+                prim_bounds.push_back(wb);
+                prim_bounded.push_back(finite ? 1 : 0);
+            }
+        }
+    }
+    for (size_t i = 0; i < prims.size(); i++) {
+        bool ok = prim_bounded[i];
+        if (ok)
+            for (int a = 0; a < 3; a++) ok = ok && std::isfinite(prim_bounds[i].lo[a]) && std::isfinite(prim_bounds[i].hi[a]);
+        prim_bounded[i] = ok;
+        if (!ok) unbounded.push_back((int32_t)i);
+    }
+    return RTC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BVH: binned SAH, binary, children adjacent, breadth-first order
+// ---------------------------------------------------------------------------------------------
+
+namespace {
+
+struct BuildNode {
+    Bounds b;
+    int left = -1, right = -1;  // temp indices
+    int first = 0, count = 0;
+};
+
+struct Builder {
+    const std::vector<Bounds> &pb;
+    std::vector<int32_t> &order;
+    std::vector<BuildNode> nodes;
+    bool median_only;
+    uint32_t max_depth = 0;
+    static constexpr int MAX_LEAF = 4;
+    static constexpr int BINS = 16;
+
+    static double area(const Bounds &b) {
+        const double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0;
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+    static void merge(Bounds &a, const Bounds &b) {
+        for (int k = 0; k < 3; k++) a.lo[k] = std::min(a.lo[k], b.lo[k]), a.hi[k] = std::max(a.hi[k], b.hi[k]);
+    }
+    static double centroid(const Bounds &b, int axis) { return 0.5 * (b.lo[axis] + b.hi[axis]); }
+
+    int build(int first, int count, uint32_t depth) {
+        const int idx = (int)nodes.size();
+        nodes.emplace_back();
+        {
+            BuildNode &n = nodes[idx];
+            n.first = first, n.count = count;
+            bounds_empty(n.b);
+            for (int i = 0; i < count; i++) merge(n.b, pb[order[first + i]]);
+        }
+        max_depth = std::max(max_depth, depth);
+        if (count <= 1) return idx;
+
+        Bounds cb;
+        bounds_empty(cb);
+        for (int i = 0; i < count; i++) {
+            const Bounds &p = pb[order[first + i]];
+            for (int k = 0; k < 3; k++) {
+                const double c = centroid(p, k);
+                cb.lo[k] = std::min(cb.lo[k], c), cb.hi[k] = std::max(cb.hi[k], c);
+            }
+        }
+        int axis = 0;
+        for (int k = 1; k < 3; k++)
+            if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+        const double extent = cb.hi[axis] - cb.lo[axis];
+
+        int mid = -1;
+        if (!median_only && extent > 0.0) {
+            // binned SAH over the three axes
+            double best_cost = std::numeric_limits<double>::infinity();
+            int best_axis = -1, best_split = -1;
+            for (int ax = 0; ax < 3; ax++) {
+                const double ext = cb.hi[ax] - cb.lo[ax];
+                if (!(ext > 0.0)) continue;
+                Bounds bb[BINS];
+                int bc[BINS];
+                for (int b = 0; b < BINS; b++) bounds_empty(bb[b]), bc[b] = 0;
+                const double scale = BINS / ext;
+                for (int i = 0; i < count; i++) {
+                    const Bounds &p = pb[order[first + i]];
+                    int b = (int)((centroid(p, ax) - cb.lo[ax]) * scale);
+                    b = std::max(0, std::min(BINS - 1, b));
+                    merge(bb[b], p);
+                    bc[b]++;
+                }
+                double right_area[BINS];
+                int right_cnt[BINS];
+                Bounds acc;
+                bounds_empty(acc);
+                int cnt = 0;
+                for (int b = BINS - 1; b >= 1; b--) {
+                    merge(acc, bb[b]);
+                    cnt += bc[b];
+                    right_area[b] = area(acc), right_cnt[b] = cnt;
+                }
+                bounds_empty(acc);
+                cnt = 0;
+                for (int b = 0; b < BINS - 1; b++) {
+                    merge(acc, bb[b]);
+                    cnt += bc[b];
+                    if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                    const double cost = area(acc) * cnt + right_area[b + 1] * right_cnt[b + 1];
+                    if (cost < best_cost) best_cost = cost, best_axis = ax, best_split = b;
+                }
+            }
+            const double leaf_cost = area(nodes[idx].b) * count;
+            // traversal step ~ 1/2 primitive test (f64 slab test vs transform + quadratic / Moeller-Trumbore)
+            if (best_axis >= 0 && (count > MAX_LEAF || best_cost + 0.5 * area(nodes[idx].b) < leaf_cost)) {
+                const double ext = cb.hi[best_axis] - cb.lo[best_axis];
+                const double scale = BINS / ext;
+                const double lo = cb.lo[best_axis];
+                auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](int32_t p) {
+                    int b = (int)((centroid(pb[p], best_axis) - lo) * scale);
+                    b = std::max(0, std::min(BINS - 1, b));
+                    return b <= best_split;
+                });
+                mid = (int)(it - order.begin());
+                if (mid == first || mid == first + count) mid = -1;
+            } else if (count <= MAX_LEAF) {
+                return idx;  // leaf is cheaper
+            }
+        }
+        if (mid < 0) {
+            if (count <= MAX_LEAF) return idx;
+            // object-median split along the widest centroid axis (also the depth-bounded fallback)
+            mid = first + count / 2;
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                             [&](int32_t a, int32_t b) {
+                                 const double ca = centroid(pb[a], axis), cbv = centroid(pb[b], axis);
+                                 return ca < cbv || (ca == cbv && a < b);
+                             });
+        }
+        const int l = build(first, mid - first, depth + 1);
+        const int r = build(mid, first + count - mid, depth + 1);
+        nodes[idx].left = l, nodes[idx].right = r;
+        return idx;
+    }
+};
+
+}  // namespace
+
+void Scene::build_bvh() {
+    bvh.clear(), bvh_prims.clear();
+    bvh_max_depth = 0, bvh_max_leaf = 0;
+    std::vector<int32_t> order;
+    for (size_t i = 0; i < prims.size(); i++)
+        if (prim_bounded[i]) order.push_back((int32_t)i);
+    if (order.empty()) return;
+
+    constexpr uint32_t DEPTH_LIMIT = 30;  // device traversal stack holds 32 entries
+    Builder b{prim_bounds, order, {}, false};
+    b.nodes.reserve(order.size() * 2);
+    b.build(0, (int)order.size(), 0);
+    if (b.max_depth > DEPTH_LIMIT) {
+        Builder m{prim_bounds, order, {}, true};
+        m.nodes.reserve(order.size() * 2);
+        m.build(0, (int)order.size(), 0);
+        b.nodes.swap(m.nodes);
+        b.max_depth = m.max_depth;
+    }
+    bvh_max_depth = b.max_depth;
+
+    // breadth-first relayout, the two children of a node adjacent (right = left + 1)
+    std::vector<int> queue{0};
+    std::vector<int> new_index(b.nodes.size(), -1);
+    new_index[0] = 0;
+    bvh.resize(1);
+    size_t head = 0;
+    while (head < queue.size()) {
+        const int t = queue[head++];
+        const BuildNode &n = b.nodes[t];
+        DBvhNode d{};
+        for (int k = 0; k < 3; k++) d.bmin[k] = n.b.lo[k], d.bmax[k] = n.b.hi[k];
+        if (n.left < 0) {
+            d.left = n.first;
+            d.count = n.count;
+            bvh_max_leaf = std::max<uint32_t>(bvh_max_leaf, (uint32_t)n.count);
+        } else {
+            const int li = (int)bvh.size();
+            bvh.resize(bvh.size() + 2);
+            new_index[n.left] = li, new_index[n.right] = li + 1;
+            queue.push_back(n.left), queue.push_back(n.right);
+            d.left = li;
+            d.count = 0;
+        }
+        bvh[new_index[t]] = d;
+    }
+    bvh_prims = order;
+    // Leaf primitives in ascending flattened index: with equal t the lower index wins anyway, but a sorted leaf
+    // lets the kernel keep the cheap strict-less test inside a leaf.
+    for (DBvhNode &n : bvh)
+        if (n.count > 0) std::sort(bvh_prims.begin() + n.left, bvh_prims.begin() + n.left + n.count);
+}
+
+// ---------------------------------------------------------------------------------------------
+// upload
+// ---------------------------------------------------------------------------------------------
+
+template <class T>
+static int upload_vec(Scene &s, const std::vector<T> &v, const T *&dptr) {
+    dptr = nullptr;
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return RTC_ERR_HIP;
+    }
+    s.device_allocs.push_back(p);
+    s.device_bytes += bytes;
+    if (!v.empty()) {
+        e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("hipMemcpy H2D failed: %s", hipGetErrorString(e));
+            return RTC_ERR_HIP;
+        }
+    }
+    dptr = (const T *)p;
+    return RTC_OK;
+}
+
+int Scene::upload(int dev) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); librtc_amd renders on the GPU only",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return RTC_ERR_NO_DEVICE;
+    }
+    if (dev >= count) {
+        set_error("HIP device %d requested, %d present", dev, count);
+        return RTC_ERR_NO_DEVICE;
+    }
+    e = hipSetDevice(dev);
+    if (e != hipSuccess) {
+        set_error("hipSetDevice(%d): %s", dev, hipGetErrorString(e));
+        return RTC_ERR_HIP;
+    }
+    device = dev;
+    dscene = DScene{};
+    dscene.cam = cam;
+    int rc;
+    if ((rc = upload_vec(*this, xforms, dscene.xforms))) return rc;
+    if ((rc = upload_vec(*this, chains, dscene.chains))) return rc;
+    if ((rc = upload_vec(*this, prims, dscene.prims))) return rc;
+    if ((rc = upload_vec(*this, tris, dscene.tris))) return rc;
+    if ((rc = upload_vec(*this, dmaterials, dscene.materials))) return rc;
+    if ((rc = upload_vec(*this, lights, dscene.lights))) return rc;
+    if ((rc = upload_vec(*this, dpatterns, dscene.patterns))) return rc;
+    if ((rc = upload_vec(*this, bvh, dscene.bvh))) return rc;
+    if ((rc = upload_vec(*this, bvh_prims, dscene.bvh_prims))) return rc;
+    if ((rc = upload_vec(*this, unbounded, dscene.unbounded))) return rc;
+    dscene.n_prims = (int32_t)prims.size();
+    dscene.n_unbounded = (int32_t)unbounded.size();
+    dscene.n_bvh_nodes = (int32_t)bvh.size();
+    dscene.n_lights = (int32_t)lights.size();
+    dscene.n_materials = (int32_t)dmaterials.size();
+    dscene.all_cast_shadow = 1;
+    dscene.any_pattern = 0;
+    for (const DMaterial &m : dmaterials) {
+        if (!m.casts_shadow) dscene.all_cast_shadow = 0;
+        if (m.pattern >= 0) dscene.any_pattern = 1;
+    }
+    std::vector<uint64_t> zeros(ST_COUNT, 0);
+    const uint64_t *dst = nullptr;
+    if ((rc = upload_vec(*this, zeros, dst))) return rc;
+    d_stats = const_cast<uint64_t *>(dst);
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        set_error("hipEventCreate failed");
+        return RTC_ERR_HIP;
+    }
+    ev_start = a, ev_stop = b;
+    return RTC_OK;
+}
+
+int Scene::commit(int dev) {
+    if (committed) {
+        set_error("scene already committed");
+        return RTC_ERR_STATE;
+    }
+    if (!open_groups.empty()) {
+        set_error("rtc_scene_commit with %zu unclosed group(s)", open_groups.size());
+        return RTC_ERR_STATE;
+    }
+    if (hsize == 0 || vsize == 0) {
+        set_error("camera hsize/vsize must be positive");
+        return RTC_ERR_INVALID;
+    }
+    int rc = flatten();
+    if (rc) return rc;
+    build_bvh();
+    if (dev >= 0) {
+        rc = upload(dev);
+        if (rc) {
+            release_device();
+            device = -1;
+            return rc;
+        }
+    }
+    committed = true;
+    return RTC_OK;
+}
+
+uint32_t local_rows(uint32_t vsize, uint32_t tile_rows, uint32_t tile_index, uint32_t tile_count) {
+    if (tile_count == 0) tile_count = 1;
+    if (tile_rows == 0 || tile_rows > vsize) tile_rows = vsize ? vsize : 1;
+    const uint32_t ntiles = (vsize + tile_rows - 1) / tile_rows;
+    uint32_t rows = 0;
+    for (uint32_t t = tile_index; t < ntiles; t += tile_count) rows += std::min(tile_rows, vsize - t * tile_rows);
+    return rows;
+}
+
+}  // namespace rtc

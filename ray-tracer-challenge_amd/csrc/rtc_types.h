@@ -1,0 +1,128 @@
+// rtc_types.h -- POD tables shared by the host flattener and the HIP kernels.
+//
+// Data layout in HBM (all tables are immutable after rtc_scene_commit, one copy per GPU):
+//   DXform[]    rows 0..2 of a cofactor inverse (96 B each); one per Group / analytic shape
+//   int chains[] root-first lists of DXform indices (a primitive's parent chain + its own transform)
+//   DPrim[]     one per leaf shape in depth-first (== reference traversal) order, 56 B
+//   DTri[]      triangle payloads (p1, e1, e2, n1..n3), 144 B
+//   DMaterial[] 88 B, DLight[] 136 B, DPattern[] 160 B
+//   DBvhNode[]  64 B binary BVH nodes over the bounded primitives (breadth-first order)
+//   int bvh_prims[] leaf -> primitive index; int unbounded[] primitives tested for every ray
+#pragma once
+#include <stdint.h>
+
+namespace rtc {
+
+enum PrimType : int32_t {
+    PT_SPHERE = 0,
+    PT_PLANE = 1,
+    PT_CUBE = 2,
+    PT_CYLINDER = 3,
+    PT_CONE = 4,
+    PT_TRIANGLE = 5,
+    PT_SMOOTH_TRIANGLE = 6
+};
+
+struct DXform {
+    double inv[12];  // inverse(T) rows 0..2, row-major 3x4
+};
+
+struct DPrim {
+    int32_t type;
+    int32_t material;
+    int32_t chain_off;  // into chains[]; root-first; for triangles the chain holds the ancestors only
+    int32_t chain_len;
+    double minimum, maximum;
+    int32_t closed;
+    int32_t tri;        // index into DTri[] or -1
+    int32_t own_xform;  // DXform index of the shape's OWN transform (pattern lookup, Q13) or -1 (triangles)
+    int32_t chain_id;   // primitives with equal chain_id share the same chain (lane-local ray cache key)
+};
+
+struct DTri {
+    double p1[3], e1[3], e2[3];
+    double n1[3], n2[3], n3[3];  // flat triangles: n1 = precomputed face normal
+};
+
+struct DMaterial {
+    double color[3];
+    double ambient, diffuse, specular, shininess;
+    double reflectivity, transparency, refractive_index;
+    int32_t casts_shadow;
+    int32_t pattern;
+};
+
+struct DLight {
+    int32_t is_area;
+    uint32_t usteps, vsteps, samples;
+    double position[3], intensity[3];
+    double corner[3], uvec[3], vvec[3];
+};
+
+struct DPattern {
+    int32_t kind;
+    int32_t sub_a, sub_b;
+    int32_t pad;
+    double a[3], b[3];
+    double inv[12];
+};
+
+struct DBvhNode {
+    double bmin[3];
+    double bmax[3];
+    int32_t left;   // internal: index of the left child (right = left + 1); leaf: first index into bvh_prims
+    int32_t count;  // 0 = internal, > 0 = leaf primitive count
+};
+
+struct DCamera {
+    double inv[12];
+    double half_width, half_height, pixel_size;
+    uint32_t hsize, vsize;
+};
+
+// Everything a kernel needs, passed by value as the kernel argument.
+struct DScene {
+    DCamera cam;
+    const DXform *xforms;
+    const int32_t *chains;
+    const DPrim *prims;
+    const DTri *tris;
+    const DMaterial *materials;
+    const DLight *lights;
+    const DPattern *patterns;
+    const DBvhNode *bvh;
+    const int32_t *bvh_prims;
+    const int32_t *unbounded;
+    int32_t n_prims, n_unbounded, n_bvh_nodes, n_lights, n_materials;
+    int32_t all_cast_shadow;  // 1 if every material has casts_shadow: shadow rays may stop at any hit
+    int32_t any_pattern;
+    int32_t pad;
+};
+
+struct DRenderParams {
+    uint32_t depth;
+    uint32_t tile_rows, tile_index, tile_count;
+    uint32_t local_rows;  // rows owned by this rank (compact output)
+    uint32_t use_bvh;     // resolved: 1 = BVH + unbounded list, 0 = brute force over all prims
+    uint32_t tiles_x, tiles_y;  // 8x8 pixel tiles covering hsize x local_rows
+};
+
+// device-side counters, one uint64 each (index constants)
+enum StatIdx {
+    ST_PRIMARY = 0,
+    ST_SHADOW,
+    ST_SECONDARY,
+    ST_SECONDARY_REF,
+    ST_CONTAINER,
+    ST_BOX,
+    ST_PRIM0,  // 7 entries
+    ST_XFORM = ST_PRIM0 + 7,
+    ST_SHADED,
+    ST_LIGHT,
+    ST_SCHLICK,
+    ST_REFRACT,
+    ST_OVERFLOW,
+    ST_COUNT
+};
+
+}  // namespace rtc
