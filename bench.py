@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render path on MI355X.
+
+Metric (BASELINE.json): Mrays/s (primary + shadow + secondary) and frame time at 4K on 1/2/4/8 GPUs.
+A "step" is one full frame: every active pixel of the workload goes through the hot path once
+(Camera::render).  Workload at every N: samples/teapot.yaml at 3840x2160 (BASELINE.json configs[3], the
+configuration the metric is quoted on; it fits one GPU).  With N > 1 the SAME frame is sharded by
+interleaved 8-row tiles over the ranks (strong scaling) and the canvas is assembled on rank 0 with an RCCL
+gather, as BASELINE.json's north_star prescribes.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Inputs (scene tables) are resident in HBM before the timed region; the timed region is K x (render kernel
+[+ gather + de-interleave on rank 0]) bracketed by barrier + synchronize; the value uses the MAX over ranks.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene file, width, height)
+    "teapot_4k": ("teapot", 3840, 2160),
+    "cover_4k": ("cover", 3840, 2160),
+    "cover_1080p": ("cover", 1920, 1080),
+    "reflective_world_1080p": ("reflective_world", 1920, 1080),
+    "ice_cream_1080p": ("ice_cream", 1920, 1080),
+}
+FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop (FMA) x 2.4 GHz; strict mode cannot use FMA
+TILE_ROWS = 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="teapot_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-stride", type=int, default=0, help="0 = choose for ~10-20 s of CPU work")
+    ap.add_argument("--extra", action="store_true", help="also time the other workloads (untimed region, N=1)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rtc = importlib.import_module("ray-tracer-challenge_amd")
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    distributed = world_size > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert world_size == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world_size}"
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    def load(workload):
+        name, w, h = WORKLOADS[workload]
+        sc = rtc.parse_scene_file(os.path.join(ROOT, "scenes", name + ".yaml"), w, h)
+        return rtc.World(sc.objects, sc.lights), sc.camera
+
+    world, cam = load(args.workload)
+    scene = cam.compile(world, device=local_rank)
+    hsize, vsize = cam.hsize, cam.vsize
+    tile = dict(tile_rows=TILE_ROWS, tile_index=rank, tile_count=world_size) if distributed else {}
+    local_rows = scene.local_rows(**tile) if distributed else vsize
+    max_rows = local_rows
+    if distributed:
+        t = torch.tensor([local_rows], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        max_rows = int(t.item())
+    buf = torch.zeros((max_rows, hsize, 3), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    gather_list = None
+    canvas_ext = None
+    index = None
+    if distributed and rank == 0:
+        gather_list = [torch.empty_like(buf) for _ in range(world_size)]
+        canvas_ext = torch.zeros((vsize + 1, hsize, 3), dtype=torch.float64, device=dev)  # +1: dump row for padding
+        idx = np.full((world_size, max_rows), vsize, dtype=np.int64)
+        for r in range(world_size):
+            m = scene.local_row_map(tile_rows=TILE_ROWS, tile_index=r, tile_count=world_size)
+            idx[r, : len(m)] = m
+        index = torch.from_numpy(idx.reshape(-1)).to(dev)
+
+    def step():
+        scene.render_device(buf.data_ptr(), stream.cuda_stream, **tile)
+        if distributed:
+            dist.gather(buf, gather_list, dst=0)
+            if rank == 0:
+                canvas_ext.index_copy_(0, index, torch.cat(gather_list, dim=0))
+
+    def sync_all():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- counters of one frame (counting kernel variant, outside the timed region) ----
+    scene.render_device(buf.data_ptr(), stream.cuda_stream, collect_stats=True, **tile)
+    st = scene.stats()
+    keys = ["primary_rays", "shadow_rays", "secondary_rays", "secondary_rays_reference", "box_tests",
+            "shaded_hits", "light_evals", "container_passes", "xform_levels", "overflow"]
+    vec = [float(st[k]) for k in keys] + [float(x) for x in st["prim_tests"]] + [st["algorithmic_flops"]]
+    if distributed:
+        t = torch.tensor(vec, device=dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        vec = t.tolist()
+    frame = dict(zip(keys, vec[: len(keys)]))
+    frame_prim_tests = vec[len(keys): len(keys) + 7]
+    frame_flops = vec[-1]
+    local_flops = st["algorithmic_flops"]
+    rays_per_frame = frame["primary_rays"] + frame["shadow_rays"] + frame["secondary_rays"]
+    assert frame["overflow"] == 0, "kernel iteration cap hit"
+
+    # ---- timed region ----
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        scene.render_device(buf.data_ptr(), stream.cuda_stream, **tile)
+        ev[i][1].record(stream)
+        if distributed:
+            dist.gather(buf, gather_list, dst=0)
+            if rank == 0:
+                canvas_ext.index_copy_(0, index, torch.cat(gather_list, dim=0))
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    if distributed:
+        t = torch.tensor([elapsed, kernel_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms_max = t.tolist()
+    else:
+        kernel_ms_max = kernel_ms
+
+    if rank != 0:
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = rays_per_frame * args.steps / elapsed / 1e6
+    achieved_tflops = local_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc, separate runs)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload if world_size == 1 else "", {}).get("bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "Mrays/s (primary+shadow+secondary), teapot.yaml @3840x2160",
+        "value": value,
+        "unit": "Mrays/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "frame_ms": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "reference sample scene (scenes/%s.yaml, camera resized)" % WORKLOADS[args.workload][0],
+        "config": {
+            "workload": "%s: scenes/%s.yaml at %dx%d, depth 5, %d active pixels" % (
+                args.workload, WORKLOADS[args.workload][0], hsize, vsize, (hsize - 1) * (vsize - 1)),
+            "sharding": "interleaved %d-row tiles over %d rank(s); RCCL gather to rank 0" % (TILE_ROWS, world_size)
+            if distributed else "single GPU, whole frame in one launch",
+            "fp_mode": "strict (no FMA contraction)",
+        },
+        "rays_per_frame": {
+            "primary": frame["primary_rays"], "shadow": frame["shadow_rays"], "secondary": frame["secondary_rays"],
+            "total_unique": rays_per_frame,
+            "secondary_reference_equivalent": frame["secondary_rays_reference"],
+        },
+        "work_per_frame": {"box_tests": frame["box_tests"], "prim_tests": frame_prim_tests,
+                           "shaded_hits": frame["shaded_hits"], "container_passes": frame["container_passes"],
+                           "algorithmic_flops": frame_flops},
+        "roofline": {
+            "bound": "fp64_valu",
+            "kernel": "rtc::k_render<false>",
+            "achieved": achieved_tflops,
+            "peak": FP64_VALU_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved_tflops / FP64_VALU_PEAK_TFLOPS,
+            "frac_of_strict_ceiling": achieved_tflops / (FP64_VALU_PEAK_TFLOPS / 2),
+            "kernel_ms": kernel_ms,
+            "kernel_ms_max_over_ranks": kernel_ms_max,
+            "algorithmic_flops_per_launch": local_flops,
+            "traffic": traffic,
+            "hbm_algorithmic_bytes_per_launch": 24.0 * hsize * local_rows,
+        },
+    }
+
+    if args.extra and not distributed:
+        extra = {}
+        for wl in WORKLOADS:
+            if wl == args.workload:
+                continue
+            w2, c2 = load(wl)
+            s2 = c2.compile(w2, device=local_rank)
+            b2 = torch.zeros((c2.vsize, c2.hsize, 3), dtype=torch.float64, device=dev)
+            s2.render_device(b2.data_ptr(), stream.cuda_stream, collect_stats=True)
+            st2 = s2.stats()
+            for _ in range(2):
+                s2.render_device(b2.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 5
+            a.record(stream)
+            for _ in range(reps):
+                s2.render_device(b2.data_ptr(), stream.cuda_stream)
+            b.record(stream)
+            torch.cuda.synchronize(dev)
+            ms = a.elapsed_time(b) / reps
+            rays = st2["primary_rays"] + st2["shadow_rays"] + st2["secondary_rays"]
+            extra[wl] = {"frame_ms": ms, "Mrays_per_s": rays / ms / 1e3, "rays": rays,
+                         "tflops": st2["algorithmic_flops"] / ms / 1e9}
+            s2.close()
+        out["extra_workloads"] = extra
+
+    if not args.no_cpu_baseline and not distributed:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import scene_feed as sf
+        threads = min(os.cpu_count() or 1, 16)
+        ow = sf.to_oracle(world, cam)
+        stride = args.cpu_sample_stride
+        if stride <= 0:
+            # probe with a coarse grid, then size the sample for ~15 s
+            ow.render(threads=threads, subset=(0, vsize, 48, 48))
+            probe = ow.last_stats
+            probe_rays = probe["primary"] + probe["shadow"] + probe["secondary"]
+            rate = probe_rays / max(probe["seconds"], 1e-6)
+            want_rays = rate * 15.0
+            est_full = probe_rays * 48 * 48
+            stride = int(max(1, min(48, round((est_full / max(want_rays, 1.0)) ** 0.5))))
+        ow.render(threads=threads, subset=(0, vsize, stride, stride))
+        cs = ow.last_stats
+        cpu_rays = cs["primary"] + cs["shadow"] + cs["secondary"]
+        out["cpu_baseline"] = {
+            "value": cpu_rays / cs["seconds"] / 1e6,
+            "unit": "Mrays/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": "C oracle (brute force, no BVH, reference recursion), every %d-th row x every %d-th column "
+                      "of the same %dx%d frame: %d rays in %.1f s" % (stride, stride, hsize, vsize, cpu_rays,
+                                                                       cs["seconds"]),
+        }
+    print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

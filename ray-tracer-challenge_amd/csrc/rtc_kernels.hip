@@ -13,6 +13,9 @@
 //     pushed on a 5-entry per-lane stack -- at most one pending entry per distinct `remaining` value;
 //   * closest hit = linear scan of the unbounded primitives + ordered traversal of a host-built binary BVH
 //     whose per-lane stack lives in LDS ([entry][lane] layout, bank-conflict free);
+//   * per lane the kernel is a state machine (closest hit -> container pass -> shadow rays -> shade) around a
+//     single inlined copy of that intersection loop, which keeps the code inside the instruction cache and
+//     lets lanes that trace different kinds of rays share instructions;
 //   * n1/n2 (intersection.rs:150-179) are computed by a second pass over the whole line t in (-inf, t_hit)
 //     in streaming form: the container list's last element is the primitive with an odd number of crossings
 //     before the hit whose last crossing is latest (see container_visit()).
@@ -30,6 +33,9 @@ namespace rtc {
 #define RTC_BVH_STACK 32
 #define RTC_MAX_DEPTH_STACK 8
 #define RTC_MAX_RAYS_PER_PIXEL 65536
+#ifndef RTC_MIN_WAVES
+#define RTC_MIN_WAVES 2  // waves per SIMD the register allocator must leave room for
+#endif
 
 struct V3 {
     double x, y, z;
@@ -252,295 +258,6 @@ DEV void isect_triangle(const Ray &r, const DTri &tr, Recs &o) {
     o.mask = 1u;
 }
 
-// ---------------------------------------------------------------------------------------------
-// per-lane state
-// ---------------------------------------------------------------------------------------------
-
-struct Counters {
-    unsigned long long c[ST_COUNT];
-};
-
-template <bool STATS>
-struct Ctx {
-    const DScene &s;
-    int *stack;  // LDS, this lane's column: stack[k * RTC_WAVE]
-    // lane-local cache of the last object-space ray (primitives of one mesh share their parent chain)
-    int cache_chain;
-    Ray cache_ray;  // reset whenever a new world ray starts (trace())
-    Counters *cnt;
-    DEV void count(int idx, unsigned long long n = 1) {
-        if (STATS) cnt->c[idx] += n;
-    }
-};
-
-// Ray::transform down the parent chain (shape.rs:2035, then the shape's own :256 etc.), root first.
-template <bool STATS>
-DEV Ray to_object(Ctx<STATS> &cx, const DPrim &p, const Ray &world) {
-    if (p.chain_len == 0) return world;
-    const bool shared_chain = p.type >= PT_TRIANGLE;  // only mesh triangles share a chain
-    if (shared_chain && p.chain_id == cx.cache_chain) return cx.cache_ray;
-    Ray r = world;
-    for (int k = 0; k < p.chain_len; k++) {
-        const double *m = cx.s.xforms[cx.s.chains[p.chain_off + k]].inv;
-        Ray q;
-        q.o = xf_point(m, r.o);
-        q.d = xf_vector(m, r.d);
-        r = q;
-    }
-    cx.count(ST_XFORM, (unsigned long long)p.chain_len);
-    if (shared_chain) {
-        cx.cache_chain = p.chain_id;
-        cx.cache_ray = r;
-    }
-    return r;
-}
-
-template <bool STATS>
-DEV void intersect_prim(Ctx<STATS> &cx, int pi, const Ray &world, Recs &rc) {
-    const DPrim &p = cx.s.prims[pi];
-    rc.mask = 0u;
-    const Ray r = to_object(cx, p, world);
-    cx.count(ST_PRIM0 + p.type);
-    switch (p.type) {
-    case PT_SPHERE: isect_sphere(r, rc); break;
-    case PT_PLANE: isect_plane(r, rc); break;
-    case PT_CUBE: isect_cube(r, rc); break;
-    case PT_CYLINDER: isect_cylinder(r, p.minimum, p.maximum, p.closed, rc); break;
-    case PT_CONE: isect_cone(r, p.minimum, p.maximum, p.closed, rc); break;
-    default: isect_triangle(r, cx.s.tris[p.tri], rc); break;
-    }
-    // records whose t is NaN can never be the hit (intersection.rs:211-214); they are dropped here
-    // (DESIGN.md "NaN records")
-    if ((rc.mask & 1u) && rc.t0 != rc.t0) rc.mask &= ~1u;
-    if ((rc.mask & 2u) && rc.t1 != rc.t1) rc.mask &= ~2u;
-    if ((rc.mask & 4u) && rc.t2 != rc.t2) rc.mask &= ~4u;
-    if ((rc.mask & 8u) && rc.t3 != rc.t3) rc.mask &= ~8u;
-}
-
-struct Hit {
-    double t;
-    int prim;
-    double u, v;
-};
-
-// hit() over this primitive's records (intersection.rs:207-219): smallest t > 0, first record wins on ties;
-// between primitives the lower flattened index wins (stable order, Q15).
-DEV void closest_visit(Hit &best, int pi, const Recs &rc) {
-#define RTC_TRY(bit, tt)                                                                      \
-    if ((rc.mask & (bit)) && (tt) > 0. && ((tt) < best.t || ((tt) == best.t && pi < best.prim))) { \
-        best.t = (tt);                                                                        \
-        best.prim = pi;                                                                       \
-        best.u = rc.u;                                                                        \
-        best.v = rc.v;                                                                        \
-    }
-    RTC_TRY(1u, rc.t0)
-    RTC_TRY(2u, rc.t1)
-    RTC_TRY(4u, rc.t2)
-    RTC_TRY(8u, rc.t3)
-#undef RTC_TRY
-}
-
-// Streaming form of the containers loop (intersection.rs:150-179).  For one primitive: count the records
-// strictly before the hit and remember the latest of them.  A primitive is "in containers" just before the
-// hit iff that count is odd, and the list's last element is the open primitive whose last record is latest
-// in the (stably) sorted order, i.e. max over (last_t, primitive index).
-struct Containers {
-    double t_hit;
-    int hit_prim;
-    double best_t;   // latest crossing among OTHER open primitives
-    int best_prim;   // -1: none
-    int hit_open;    // hit primitive has an odd number of records before the hit
-    double hit_last;
-};
-DEV void container_visit(Containers &c, int pi, const Recs &rc) {
-    int n = 0;
-    double last = 0.;
-#define RTC_CNT(bit, tt)                          \
-    if ((rc.mask & (bit)) && (tt) < c.t_hit) {    \
-        if (n == 0 || (tt) >= last) last = (tt);  \
-        n++;                                      \
-    }
-    RTC_CNT(1u, rc.t0)
-    RTC_CNT(2u, rc.t1)
-    RTC_CNT(4u, rc.t2)
-    RTC_CNT(8u, rc.t3)
-#undef RTC_CNT
-    if (!(n & 1)) return;
-    if (pi == c.hit_prim) {
-        c.hit_open = 1;
-        c.hit_last = last;
-    } else if (c.best_prim < 0 || last > c.best_t || (last == c.best_t && pi > c.best_prim)) {
-        c.best_t = last;
-        c.best_prim = pi;
-    }
-}
-
-// Slab test against a padded world-space box.  fmin/fmax drop NaNs (0 * inf on a boundary plane), which
-// keeps the test conservative.
-DEV bool box_interval(const DBvhNode &n, const V3 &o, const V3 &inv_d, double lo, double hi, double &tnear) {
-    double t1 = (n.bmin[0] - o.x) * inv_d.x, t2 = (n.bmax[0] - o.x) * inv_d.x;
-    double tn = fmin(t1, t2), tf = fmax(t1, t2);
-    t1 = (n.bmin[1] - o.y) * inv_d.y, t2 = (n.bmax[1] - o.y) * inv_d.y;
-    tn = fmax(tn, fmin(t1, t2)), tf = fmin(tf, fmax(t1, t2));
-    t1 = (n.bmin[2] - o.z) * inv_d.z, t2 = (n.bmax[2] - o.z) * inv_d.z;
-    tn = fmax(tn, fmin(t1, t2)), tf = fmin(tf, fmax(t1, t2));
-    tnear = tn;
-    return tn <= tf && tn <= hi && tf >= lo;
-}
-
-enum TraceMode { TM_CLOSEST = 0, TM_ANY = 1, TM_CONTAINER = 2 };
-
-// World::intersect (world.rs:176-186) without materialising the list.
-//   TM_CLOSEST: nearest record with 0 < t < best.t (best.t preset to the search bound)
-//   TM_ANY:     stop at the first record with 0 < t < best.t
-//   TM_CONTAINER: visit every primitive with a record t < cont.t_hit
-template <int MODE, bool STATS>
-DEV void trace(Ctx<STATS> &cx, const Ray &ray, bool use_bvh, Hit &best, Containers &cont) {
-    const DScene &s = cx.s;
-    cx.cache_chain = -1;
-    Recs rc;
-    rc.t0 = rc.t1 = rc.t2 = rc.t3 = 0.;
-    rc.u = rc.v = 0.;
-    const int n_linear = use_bvh ? s.n_unbounded : s.n_prims;
-    for (int i = 0; i < n_linear; i++) {
-        const int pi = use_bvh ? s.unbounded[i] : i;
-        intersect_prim(cx, pi, ray, rc);
-        if (MODE == TM_CONTAINER) {
-            container_visit(cont, pi, rc);
-        } else {
-            closest_visit(best, pi, rc);
-            if (MODE == TM_ANY && best.prim >= 0) return;
-        }
-    }
-    if (!use_bvh || s.n_bvh_nodes == 0) return;
-
-    const double inf = __longlong_as_double(0x7ff0000000000000LL);
-    const V3 inv_d = mk(1. / ray.d.x, 1. / ray.d.y, 1. / ray.d.z);
-    const double lo = (MODE == TM_CONTAINER) ? -inf : 0.;
-    int sp = 0;
-    int node = 0;
-    {
-        double tn;
-        cx.count(ST_BOX);
-        if (!box_interval(s.bvh[0], ray.o, inv_d, lo, (MODE == TM_CONTAINER) ? cont.t_hit : best.t, tn)) return;
-    }
-    for (;;) {
-        const DBvhNode &n = s.bvh[node];
-        const int count = n.count, left = n.left;
-        bool pop = true;
-        if (count > 0) {
-            for (int k = 0; k < count; k++) {
-                const int pi = s.bvh_prims[left + k];
-                intersect_prim(cx, pi, ray, rc);
-                if (MODE == TM_CONTAINER) {
-                    container_visit(cont, pi, rc);
-                } else {
-                    closest_visit(best, pi, rc);
-                    if (MODE == TM_ANY && best.prim >= 0) return;
-                }
-            }
-        } else {
-            const double hi = (MODE == TM_CONTAINER) ? cont.t_hit : best.t;
-            double tl, tr;
-            cx.count(ST_BOX, 2);
-            const bool hl = box_interval(s.bvh[left], ray.o, inv_d, lo, hi, tl);
-            const bool hr = box_interval(s.bvh[left + 1], ray.o, inv_d, lo, hi, tr);
-            if (hl && hr) {
-                const bool left_first = (MODE == TM_CONTAINER) ? true : (tl <= tr);
-                const int far = left_first ? left + 1 : left;
-                node = left_first ? left : left + 1;
-                if (sp < RTC_BVH_STACK) cx.stack[sp * RTC_WAVE] = far, sp++;
-                pop = false;
-            } else if (hl || hr) {
-                node = hl ? left : left + 1;
-                pop = false;
-            }
-        }
-        if (pop) {
-            // pop until a node that can still matter
-            for (;;) {
-                if (sp == 0) return;
-                sp--;
-                node = cx.stack[sp * RTC_WAVE];
-                if (MODE == TM_CONTAINER) break;
-                double tn;
-                cx.count(ST_BOX);
-                if (box_interval(s.bvh[node], ray.o, inv_d, lo, best.t, tn)) break;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// shading
-// ---------------------------------------------------------------------------------------------
-
-// Shape::normal_at (shape.rs:43-47): world_to_object down the chain (shape.rs:82-90), local normal,
-// normal_to_world back up with a normalisation per level (shape.rs:94-103).
-template <bool STATS>
-DEV V3 normal_at(Ctx<STATS> &cx, const DPrim &p, V3 world_point, double hu, double hv) {
-    const DScene &s = cx.s;
-    V3 n;
-    if (p.type >= PT_TRIANGLE) {
-        const DTri &tr = s.tris[p.tri];
-        if (p.type == PT_TRIANGLE) {
-            n = ld3(tr.n1);  // shape.rs:1516-1518
-        } else {             // shape.rs:1749-1754
-            n = ld3(tr.n2) * hu + ld3(tr.n3) * hv + ld3(tr.n1) * (1. - hu - hv);
-        }
-        // the triangle's own transformation() is the identity (shape.rs:1550-1552): only the normalisation
-        // of that level remains
-        n = normalize(n);
-    } else {
-        V3 lp = world_point;
-        for (int k = 0; k < p.chain_len; k++) lp = xf_point(s.xforms[s.chains[p.chain_off + k]].inv, lp);
-        switch (p.type) {
-        case PT_SPHERE: n = lp - mk(0., 0., 0.); break;  // shape.rs:273-279
-        case PT_PLANE: n = mk(0., 1., 0.); break;         // shape.rs:550-553
-        case PT_CUBE: {                                   // shape.rs:743-757
-            const double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
-            const double mc = max3_total(ax, ay, az);
-            if (mc == ax)
-                n = mk(lp.x, 0., 0.);
-            else if (mc == ay)
-                n = mk(0., lp.y, 0.);
-            else
-                n = mk(0., 0., lp.z);
-            break;
-        }
-        case PT_CYLINDER: {  // shape.rs:983-998
-            const double dist = lp.x * lp.x + lp.z * lp.z;
-            if (dist < 1. && lp.y >= p.maximum - RTC_EPS)
-                n = mk(0., 1., 0.);
-            else if (dist < 1. && lp.y <= p.minimum + RTC_EPS)
-                n = mk(0., -1., 0.);
-            else
-                n = mk(lp.x, 0., lp.z);
-            break;
-        }
-        default: {  // PT_CONE, shape.rs:1302-1314
-            const double dist = lp.x * lp.x + lp.z * lp.z;
-            if (dist < 1. && lp.y >= p.maximum - RTC_EPS)
-                n = mk(0., 1., 0.);
-            else if (dist < 1. && lp.y <= p.minimum + RTC_EPS)
-                n = mk(0., -1., 0.);
-            else {
-                double y = sqrt(lp.x * lp.x + lp.z * lp.z);
-                y = (lp.y > 0.) ? -y : y;
-                n = mk(lp.x, y, lp.z);
-            }
-            break;
-        }
-        }
-        // own level
-        n = normalize(xf_normal(s.xforms[s.chains[p.chain_off + p.chain_len - 1]].inv, n));
-    }
-    // ancestors, innermost first
-    const int first_parent = (p.type >= PT_TRIANGLE) ? p.chain_len - 1 : p.chain_len - 2;
-    for (int k = first_parent; k >= 0; k--) n = normalize(xf_normal(s.xforms[s.chains[p.chain_off + k]].inv, n));
-    return n;
-}
-
 // Rust's `%` on f64 is fmod; pattern.rs kinds
 DEV V3 pattern_eval(const DScene &s, int pi, V3 p) {
     // Stripe / Checker select a sub-pattern and evaluate it at the same point (pattern.rs:114-121, 380-386);
@@ -646,46 +363,99 @@ DEV double schlick(double n1, double n2, V3 eye, V3 normal) {
     return r0 + (1. - r0) * (x * (x2 * x2));  // powi(5)
 }
 
+// ---------------------------------------------------------------------------------------------
+// per-lane helpers
+// ---------------------------------------------------------------------------------------------
+
+struct Hit {
+    double t;
+    int prim;
+    double u, v;
+};
+
+// hit() over this primitive's records (intersection.rs:207-219): smallest t > 0, first record wins on ties;
+// between primitives the lower flattened index wins (stable order, Q15).
+DEV void closest_visit(Hit &best, int pi, const Recs &rc) {
+#define RTC_TRY(bit, tt)                                                                      \
+    if ((rc.mask & (bit)) && (tt) > 0. && ((tt) < best.t || ((tt) == best.t && pi < best.prim))) { \
+        best.t = (tt);                                                                        \
+        best.prim = pi;                                                                       \
+        best.u = rc.u;                                                                        \
+        best.v = rc.v;                                                                        \
+    }
+    RTC_TRY(1u, rc.t0)
+    RTC_TRY(2u, rc.t1)
+    RTC_TRY(4u, rc.t2)
+    RTC_TRY(8u, rc.t3)
+#undef RTC_TRY
+}
+
+// Streaming form of the containers loop (intersection.rs:150-179).  For one primitive: count the records
+// strictly before the hit and remember the latest of them.  A primitive is "in containers" just before the
+// hit iff that count is odd, and the list's last element is the open primitive whose last record is latest
+// in the (stably) sorted order, i.e. max over (last_t, primitive index).
+struct Containers {
+    double t_hit;
+    int hit_prim;
+    double best_t;   // latest crossing among OTHER open primitives
+    int best_prim;   // -1: none
+    int hit_open;    // hit primitive has an odd number of records before the hit
+    double hit_last;
+};
+DEV void container_visit(Containers &c, int pi, const Recs &rc) {
+    int n = 0;
+    double last = 0.;
+#define RTC_CNT(bit, tt)                          \
+    if ((rc.mask & (bit)) && (tt) < c.t_hit) {    \
+        if (n == 0 || (tt) >= last) last = (tt);  \
+        n++;                                      \
+    }
+    RTC_CNT(1u, rc.t0)
+    RTC_CNT(2u, rc.t1)
+    RTC_CNT(4u, rc.t2)
+    RTC_CNT(8u, rc.t3)
+#undef RTC_CNT
+    if (!(n & 1)) return;
+    if (pi == c.hit_prim) {
+        c.hit_open = 1;
+        c.hit_last = last;
+    } else if (c.best_prim < 0 || last > c.best_t || (last == c.best_t && pi > c.best_prim)) {
+        c.best_t = last;
+        c.best_prim = pi;
+    }
+}
+
+// Slab test of a padded world-space box.  This is the build's own culling arithmetic, not reference
+// arithmetic: it uses FMA and an approximate reciprocal; the 1e-6 relative padding of the boxes (host) is ten
+// orders of magnitude above its rounding error.  fmin/fmax drop NaNs, which keeps the test conservative.
+DEV bool slab(const double *bmin, const double *bmax, const V3 &inv_d, const V3 &oi, double lo, double hi,
+              double &tnear) {
+    double t1 = fma(bmin[0], inv_d.x, oi.x), t2 = fma(bmax[0], inv_d.x, oi.x);
+    double tn = fmin(t1, t2), tf = fmax(t1, t2);
+    t1 = fma(bmin[1], inv_d.y, oi.y), t2 = fma(bmax[1], inv_d.y, oi.y);
+    tn = fmax(tn, fmin(t1, t2)), tf = fmin(tf, fmax(t1, t2));
+    t1 = fma(bmin[2], inv_d.z, oi.z), t2 = fma(bmax[2], inv_d.z, oi.z);
+    tn = fmax(tn, fmin(t1, t2)), tf = fmin(tf, fmax(t1, t2));
+    tnear = tn;
+    return tn <= tf && tn <= hi && tf >= lo;
+}
+DEV double safe_rcp(double d) {
+    const double r = __builtin_amdgcn_rcp(d);
+    const double a = fmin(fabs(r), 1e30);  // d == 0 (or denormal): a huge finite slope keeps fma() NaN-free
+    return copysign(a, d);
+}
+
+struct Counters {
+    unsigned long long c[ST_COUNT];
+};
+
 struct Pending {
     V3 o, d;
     double w, mult;
     int remaining;
 };
 
-// World::is_shadowed (world.rs:78-91): only the NEAREST positive hit is consulted (Q5).  When every material
-// casts shadows, "nearest hit has t < distance" is equivalent to "some hit has 0 < t < distance".
-template <bool STATS>
-DEV bool is_shadowed(Ctx<STATS> &cx, V3 point, V3 light_pos, bool use_bvh) {
-    const V3 dv = light_pos - point;
-    const double distance = magnitude(dv);
-    Ray r;
-    r.o = point;
-    r.d = normalize(dv);
-    Hit h;
-    h.t = distance, h.prim = -1, h.u = h.v = 0.;
-    Containers dummy;
-    cx.count(ST_SHADOW);
-    if (cx.s.all_cast_shadow) {
-        trace<TM_ANY, STATS>(cx, r, use_bvh, h, dummy);
-        return h.prim >= 0;
-    }
-    trace<TM_CLOSEST, STATS>(cx, r, use_bvh, h, dummy);
-    return h.prim >= 0 && cx.s.materials[cx.s.prims[h.prim].material].casts_shadow != 0;
-}
-
-// Light::intensity_at: PointLight light.rs:50-56, AreaLight light.rs:112-125
-template <bool STATS>
-DEV double intensity_at(Ctx<STATS> &cx, const DLight &l, V3 point, bool use_bvh) {
-    if (!l.is_area) return is_shadowed(cx, point, ld3(l.position), use_bvh) ? 0. : 1.;
-    double total = 0.;
-    for (unsigned v = 0; v < l.vsteps; v++)
-        for (unsigned u = 0; u < l.usteps; u++) {
-            // light.rs:106-108
-            const V3 lp = ld3(l.corner) + ld3(l.uvec) * ((double)u + 0.5) + ld3(l.vvec) * ((double)v + 0.5);
-            if (!is_shadowed(cx, point, lp, use_bvh)) total += 1.;
-        }
-    return total / (double)l.samples;
-}
+enum Mode { MODE_CLOSEST = 0, MODE_SHADOW = 1, MODE_CONTAINER = 2 };
 
 // canvas row of this rank's local row l (interleaved row tiles)
 DEV unsigned canvas_row(const DRenderParams &p, unsigned l) {
@@ -694,11 +464,23 @@ DEV unsigned canvas_row(const DRenderParams &p, unsigned l) {
     return (k * p.tile_count + p.tile_index) * p.tile_rows + (l - k * p.tile_rows);
 }
 
+#define CNT(idx, n)                                   \
+    do {                                              \
+        if (STATS) cnt.c[idx] += (unsigned long long)(n); \
+    } while (0)
+
+// The megakernel.  Per lane it is a small state machine around ONE copy of the intersection loop:
+//   MODE_CLOSEST   World::color_at's closest hit for a primary / reflect / refract ray
+//   MODE_CONTAINER second pass over the same ray for n1/n2 (only for transparent hits)
+//   MODE_SHADOW    World::is_shadowed for one light sample
+// so lanes tracing different kinds of rays still execute the same instructions.
 template <bool STATS>
-__global__ __launch_bounds__(RTC_WAVE) void k_render(DScene s, DRenderParams prm, double *__restrict__ out,
-                                                      unsigned long long *__restrict__ stats) {
+__global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DRenderParams prm,
+                                                                     double *__restrict__ out,
+                                                                     unsigned long long *__restrict__ stats) {
     __shared__ int bvh_stack[RTC_BVH_STACK * RTC_WAVE];
     const unsigned lane = threadIdx.x;
+    int *const stack = &bvh_stack[lane];  // [entry][lane]: conflict free
     const unsigned tile = blockIdx.x;
     const unsigned tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
     const unsigned x = tx * 8u + (lane & 7u);
@@ -706,153 +488,394 @@ __global__ __launch_bounds__(RTC_WAVE) void k_render(DScene s, DRenderParams prm
     const bool in_image = x < s.cam.hsize && l < prm.local_rows;
     const unsigned y = canvas_row(prm, l);
     // camera.rs:72,78: rows 0..vsize-1 and columns 0..hsize-1 (exclusive) -- Q1
-    const bool active = in_image && (x + 1u < s.cam.hsize) && (y + 1u < s.cam.vsize);
+    bool alive = in_image && (x + 1u < s.cam.hsize) && (y + 1u < s.cam.vsize);
     const bool use_bvh = prm.use_bvh != 0;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
 
     Counters cnt;
     if (STATS)
         for (int i = 0; i < ST_COUNT; i++) cnt.c[i] = 0;
-    Ctx<STATS> cx{s, &bvh_stack[lane], -1, Ray{}, &cnt};
 
+    // ---- path state ----
     V3 color = mk(0., 0., 0.);
-    if (active) {
+    double w = 1., mult = 1.;
+    int remaining = (int)prm.depth;
+    Pending pend[RTC_MAX_DEPTH_STACK];
+    int sp = 0;
+    int rays = 0;
+    const double nl = (double)s.n_lights;
+    // ---- current ray ----
+    Ray ray;
+    ray.o = ray.d = mk(0., 0., 0.);
+    int mode = MODE_CLOSEST;
+    Hit best;
+    best.t = inf, best.prim = -1, best.u = best.v = 0.;
+    Containers cont;
+    cont.t_hit = 0., cont.hit_prim = -1, cont.best_t = 0., cont.best_prim = -1, cont.hit_open = 0, cont.hit_last = 0.;
+    // ---- shading context (valid from the closest hit until the last shadow ray of that hit) ----
+    int h_prim = -1;
+    V3 h_point = mk(0., 0., 0.), h_eye = mk(0., 0., 0.), h_normal = mk(0., 0., 0.);
+    double h_n1 = 1., h_n2 = 1.;
+    V3 surface = mk(0., 0., 0.);
+    int li = 0;
+    unsigned su = 0, sv = 0;
+    double total = 0.;
+
+    if (alive) {
         // Camera::ray_for_pixel, camera.rs:41-59
-        Ray ray;
+        const double xo = ((double)x + 0.5) * s.cam.pixel_size;
+        const double yo = ((double)y + 0.5) * s.cam.pixel_size;
+        const double wx = s.cam.half_width - xo;
+        const double wy = s.cam.half_height - yo;
+        const V3 pixel = xf_point(s.cam.inv, mk(wx, wy, -1.));
+        ray.o = xf_point(s.cam.inv, mk(0., 0., 0.));
+        ray.d = normalize(pixel - ray.o);
+        CNT(ST_PRIMARY, 1);
+        rays = 1;
+    }
+
+    while (alive) {
+        // =====================================================================================
+        // World::intersect (world.rs:176-186) without materialising the list: linear run over the
+        // unbounded primitives, then ordered BVH traversal; one inlined copy serves all three modes.
+        // =====================================================================================
         {
-            const double xo = ((double)x + 0.5) * s.cam.pixel_size;
-            const double yo = ((double)y + 0.5) * s.cam.pixel_size;
-            const double wx = s.cam.half_width - xo;
-            const double wy = s.cam.half_height - yo;
-            const V3 pixel = xf_point(s.cam.inv, mk(wx, wy, -1.));
-            ray.o = xf_point(s.cam.inv, mk(0., 0., 0.));
-            ray.d = normalize(pixel - ray.o);
-        }
-        cx.count(ST_PRIMARY);
-        const double inf = __longlong_as_double(0x7ff0000000000000LL);
-        double w = 1., mult = 1.;
-        int remaining = (int)prm.depth;
-        Pending pend[RTC_MAX_DEPTH_STACK];
-        int sp = 0;
-        int rays = 0;
-        const double nl = (double)s.n_lights;
-        for (;;) {
-            if (++rays > RTC_MAX_RAYS_PER_PIXEL) {
-                cx.count(ST_OVERFLOW);
-                if (!STATS) color = mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.);
-                break;
+            const int32_t *__restrict__ list = use_bvh ? s.prim_list : s.all_list;
+            int pos = 0, end = use_bvh ? s.n_unbounded : s.n_prims;
+            bool root_pending = use_bvh && s.n_bounded > 0;
+            int sb = 0;
+            const double lo = (mode == MODE_CONTAINER) ? -inf : 0.;
+            const bool any_hit = (mode == MODE_SHADOW) && s.all_cast_shadow;
+            V3 inv_d = mk(0., 0., 0.), oi = mk(0., 0., 0.);
+            if (root_pending) {
+                inv_d = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
+                oi = mk(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z);
             }
+            int cache_chain = -1;
+            Ray cache_ray = ray;
+            for (;;) {
+                if (pos < end) {
+                    const int pi = list[pos++];
+                    const DPrim &p = s.prims[pi];
+                    // Ray::transform down the parent chain, root first (shape.rs:2035, then :256 etc.).
+                    // Triangles of one mesh share their chain: the object-space ray is cached per lane.
+                    Ray r = ray;
+                    if (p.chain_len > 0) {
+                        const bool shared = p.type >= PT_TRIANGLE;
+                        if (shared && p.chain_id == cache_chain) {
+                            r = cache_ray;
+                        } else {
+                            for (int k = 0; k < p.chain_len; k++) {
+                                const double *m = s.xforms[s.chains[p.chain_off + k]].inv;
+                                Ray q;
+                                q.o = xf_point(m, r.o);
+                                q.d = xf_vector(m, r.d);
+                                r = q;
+                            }
+                            CNT(ST_XFORM, p.chain_len);
+                            if (shared) cache_chain = p.chain_id, cache_ray = r;
+                        }
+                    }
+                    CNT(ST_PRIM0 + p.type, 1);
+                    Recs rc;
+                    rc.t0 = rc.t1 = rc.t2 = rc.t3 = 0.;
+                    rc.u = rc.v = 0.;
+                    rc.mask = 0u;
+                    switch (p.type) {
+                    case PT_SPHERE: isect_sphere(r, rc); break;
+                    case PT_PLANE: isect_plane(r, rc); break;
+                    case PT_CUBE: isect_cube(r, rc); break;
+                    case PT_CYLINDER: isect_cylinder(r, p.minimum, p.maximum, p.closed, rc); break;
+                    case PT_CONE: isect_cone(r, p.minimum, p.maximum, p.closed, rc); break;
+                    default: isect_triangle(r, s.tris[p.tri], rc); break;
+                    }
+                    // records whose t is NaN can never be the hit (intersection.rs:211-214); dropped
+                    // (DESIGN.md "NaN records")
+                    if (rc.t0 != rc.t0) rc.mask &= ~1u;
+                    if (rc.t1 != rc.t1) rc.mask &= ~2u;
+                    if (rc.t2 != rc.t2) rc.mask &= ~4u;
+                    if (rc.t3 != rc.t3) rc.mask &= ~8u;
+                    if (mode == MODE_CONTAINER) {
+                        container_visit(cont, pi, rc);
+                    } else {
+                        closest_visit(best, pi, rc);
+                        if (any_hit && best.prim >= 0) break;
+                    }
+                    continue;
+                }
+                // ---- next leaf ----
+                int ref;
+                if (root_pending) {
+                    root_pending = false;
+                    double tn;
+                    CNT(ST_BOX, 1);
+                    if (!slab(s.root_min, s.root_max, inv_d, oi, lo, (mode == MODE_CONTAINER) ? cont.t_hit : best.t, tn))
+                        break;
+                    ref = s.root_ref;
+                } else if (sb > 0) {
+                    sb--;
+                    ref = stack[sb * RTC_WAVE];
+                } else {
+                    break;
+                }
+                bool finished = false;
+                while (ref >= 0) {
+                    const DBvhNode &n = s.bvh[ref];
+                    const double hi = (mode == MODE_CONTAINER) ? cont.t_hit : best.t;
+                    double tl, tr;
+                    CNT(ST_BOX, 2);
+                    const bool hl = slab(n.lmin, n.lmax, inv_d, oi, lo, hi, tl);
+                    const bool hr = slab(n.rmin, n.rmax, inv_d, oi, lo, hi, tr);
+                    const int cl = n.left, cr = n.right;
+                    if (hl && hr) {
+                        const bool left_first = tl <= tr;
+                        if (sb < RTC_BVH_STACK) stack[sb * RTC_WAVE] = left_first ? cr : cl, sb++;
+                        ref = left_first ? cl : cr;
+                    } else if (hl) {
+                        ref = cl;
+                    } else if (hr) {
+                        ref = cr;
+                    } else if (sb > 0) {
+                        sb--;
+                        ref = stack[sb * RTC_WAVE];
+                    } else {
+                        finished = true;
+                        break;
+                    }
+                }
+                if (finished) break;
+                const int code = ~ref;
+                pos = code >> 3;
+                end = pos + (code & 7) + 1;
+            }
+        }
+
+        // =====================================================================================
+        // state machine
+        // =====================================================================================
+        bool begin_lights = false, finish = false, next_ray = false, need_shadow = false;
+        if (mode == MODE_CLOSEST) {
             // World::color_at, world.rs:30-38
-            Hit h;
-            h.t = inf, h.prim = -1, h.u = h.v = 0.;
-            Containers cont;
-            trace<TM_CLOSEST, STATS>(cx, ray, use_bvh, h, cont);
-            bool follow = false;
-            if (h.prim >= 0 && s.n_lights > 0) {
-                const DPrim &p = s.prims[h.prim];
+            if (best.prim < 0 || s.n_lights == 0) {
+                next_ray = true;
+            } else {
+                const DPrim &p = s.prims[best.prim];
                 const DMaterial &m = s.materials[p.material];
                 // Intersection::prepare_computations, intersection.rs:123-148
-                const V3 point = ray.o + ray.d * h.t;
-                const V3 eye = -ray.d;
-                V3 normal = normal_at(cx, p, point, h.u, h.v);
-                if (dot(normal, eye) < 0.) normal = -normal;
-                const V3 reflectv = reflect(ray.d, normal);
-                const V3 over = point + normal * RTC_EPS;
-                const V3 under = point - normal * RTC_EPS;
-                cx.count(ST_SHADED);
-
-                // World::shade_hit, world.rs:42-76 -- surface terms, left fold over the lights
-                V3 surface = mk(0., 0., 0.);
-                const V3 base = ld3(m.color);
-                for (int li = 0; li < s.n_lights; li++) {
-                    const DLight &lt = s.lights[li];
-                    const double inten = intensity_at(cx, lt, over, use_bvh);
-                    const V3 col = (m.pattern >= 0) ? pattern_at_shape(s, m.pattern, p, over) : base;
-                    const V3 c = lighting(m, col, ld3(lt.position), ld3(lt.intensity), over, eye, normal, inten);
-                    cx.count(ST_LIGHT);
-                    surface = (li == 0) ? c : surface + c;
+                h_prim = best.prim;
+                h_point = ray.o + ray.d * best.t;
+                h_eye = -ray.d;
+                // Shape::normal_at (shape.rs:43-47): world_to_object down the chain (shape.rs:82-90), local
+                // normal, normal_to_world back up with a normalisation per level (shape.rs:94-103).
+                V3 n;
+                if (p.type >= PT_TRIANGLE) {
+                    const DTri &tr = s.tris[p.tri];
+                    if (p.type == PT_TRIANGLE)
+                        n = ld3(tr.n1);  // shape.rs:1516-1518
+                    else                 // shape.rs:1749-1754
+                        n = ld3(tr.n2) * best.u + ld3(tr.n3) * best.v + ld3(tr.n1) * (1. - best.u - best.v);
+                    // the triangle's own transformation() is the identity (shape.rs:1550-1552): only that
+                    // level's normalisation remains
+                    n = normalize(n);
+                } else {
+                    V3 lp = h_point;
+                    for (int k = 0; k < p.chain_len; k++) lp = xf_point(s.xforms[s.chains[p.chain_off + k]].inv, lp);
+                    switch (p.type) {
+                    case PT_SPHERE: n = lp - mk(0., 0., 0.); break;  // shape.rs:273-279
+                    case PT_PLANE: n = mk(0., 1., 0.); break;         // shape.rs:550-553
+                    case PT_CUBE: {                                   // shape.rs:743-757
+                        const double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
+                        const double mc = max3_total(ax, ay, az);
+                        if (mc == ax)
+                            n = mk(lp.x, 0., 0.);
+                        else if (mc == ay)
+                            n = mk(0., lp.y, 0.);
+                        else
+                            n = mk(0., 0., lp.z);
+                        break;
+                    }
+                    default: {  // PT_CYLINDER shape.rs:983-998, PT_CONE shape.rs:1302-1314 (Q8: dist < 1)
+                        const double dist = lp.x * lp.x + lp.z * lp.z;
+                        if (dist < 1. && lp.y >= p.maximum - RTC_EPS)
+                            n = mk(0., 1., 0.);
+                        else if (dist < 1. && lp.y <= p.minimum + RTC_EPS)
+                            n = mk(0., -1., 0.);
+                        else if (p.type == PT_CYLINDER)
+                            n = mk(lp.x, 0., lp.z);
+                        else {
+                            double yy = sqrt(lp.x * lp.x + lp.z * lp.z);
+                            yy = (lp.y > 0.) ? -yy : yy;
+                            n = mk(lp.x, yy, lp.z);
+                        }
+                        break;
+                    }
+                    }
+                    n = normalize(xf_normal(s.xforms[s.chains[p.chain_off + p.chain_len - 1]].inv, n));
                 }
-                color = color + surface * w;
-
-                // reflected_color / refracted_color, world.rs:93-147.  The reference evaluates both inside the
-                // per-light loop (Q3), i.e. adds them n_lights times: the factor goes into the child's weight.
-                if (remaining > 0) {
-                    const bool refl = m.reflectivity != 0.;
-                    const bool refr = m.transparency != 0.;
-                    double kr = 1., kt = 1.;
-                    double n1 = 1., n2 = 1.;
-                    if (refr) {
-                        // containers loop in streaming form
-                        cont.t_hit = h.t, cont.hit_prim = h.prim;
-                        cont.best_t = 0., cont.best_prim = -1, cont.hit_open = 0, cont.hit_last = 0.;
-                        Hit unused;
-                        unused.t = inf, unused.prim = -1, unused.u = unused.v = 0.;
-                        cx.count(ST_CONTAINER);
-                        trace<TM_CONTAINER, STATS>(cx, ray, use_bvh, unused, cont);
-                        const double ri_hit = m.refractive_index;
-                        const double ri_other =
-                            (cont.best_prim >= 0) ? s.materials[s.prims[cont.best_prim].material].refractive_index : 1.;
-                        if (cont.hit_open) {
-                            // the hit primitive leaves: n1 = last of (others + hit), n2 = last of others
-                            const bool hit_is_last =
-                                cont.best_prim < 0 || cont.hit_last > cont.best_t ||
-                                (cont.hit_last == cont.best_t && h.prim > cont.best_prim);
-                            n1 = hit_is_last ? ri_hit : ri_other;
-                            n2 = ri_other;
+                const int first_parent = (p.type >= PT_TRIANGLE) ? p.chain_len - 1 : p.chain_len - 2;
+                for (int k = first_parent; k >= 0; k--)
+                    n = normalize(xf_normal(s.xforms[s.chains[p.chain_off + k]].inv, n));
+                if (dot(n, h_eye) < 0.) n = -n;  // intersection.rs:134-139
+                h_normal = n;
+                h_n1 = h_n2 = 1.;
+                CNT(ST_SHADED, 1);
+                if (remaining > 0 && m.transparency != 0.) {
+                    // containers loop (intersection.rs:150-179) in streaming form: second pass over the same ray
+                    cont.t_hit = best.t, cont.hit_prim = best.prim;
+                    cont.best_t = 0., cont.best_prim = -1, cont.hit_open = 0, cont.hit_last = 0.;
+                    mode = MODE_CONTAINER;
+                    CNT(ST_CONTAINER, 1);
+                    continue;
+                }
+                begin_lights = true;
+            }
+        } else if (mode == MODE_CONTAINER) {
+            const double ri_hit = s.materials[s.prims[h_prim].material].refractive_index;
+            const double ri_other =
+                (cont.best_prim >= 0) ? s.materials[s.prims[cont.best_prim].material].refractive_index : 1.;
+            if (cont.hit_open) {
+                // the hit primitive leaves: n1 = last of (others + hit), n2 = last of the others
+                const bool hit_is_last = cont.best_prim < 0 || cont.hit_last > cont.best_t ||
+                                         (cont.hit_last == cont.best_t && h_prim > cont.best_prim);
+                h_n1 = hit_is_last ? ri_hit : ri_other;
+                h_n2 = ri_other;
+            } else {
+                // the hit primitive enters and becomes the last container
+                h_n1 = ri_other;
+                h_n2 = ri_hit;
+            }
+            begin_lights = true;
+        } else {
+            // World::is_shadowed (world.rs:78-91): only the NEAREST positive hit is consulted (Q5); when every
+            // material casts shadows that equals "some hit has 0 < t < distance" (any-hit early exit).
+            const bool shadowed =
+                best.prim >= 0 && (s.all_cast_shadow || s.materials[s.prims[best.prim].material].casts_shadow != 0);
+            const DLight &lt = s.lights[li];
+            bool have = true;
+            double inten;
+            if (lt.is_area) {  // light.rs:112-125
+                if (!shadowed) total += 1.;
+                su++;
+                if (su >= lt.usteps) su = 0, sv++;
+                if (sv < lt.vsteps) {
+                    have = false;
+                    need_shadow = true;
+                }
+                inten = total / (double)lt.samples;
+            } else {  // light.rs:50-56
+                inten = shadowed ? 0. : 1.;
+            }
+            if (have) {
+                const DPrim &p = s.prims[h_prim];
+                const DMaterial &m = s.materials[p.material];
+                const V3 over = h_point + h_normal * RTC_EPS;
+                const V3 col = (m.pattern >= 0) ? pattern_at_shape(s, m.pattern, p, over) : ld3(m.color);
+                const V3 c = lighting(m, col, ld3(lt.position), ld3(lt.intensity), over, h_eye, h_normal, inten);
+                CNT(ST_LIGHT, 1);
+                surface = (li == 0) ? c : surface + c;  // world.rs:70 left fold
+                li++;
+                su = sv = 0;
+                total = 0.;
+                if (li < s.n_lights)
+                    need_shadow = true;
+                else
+                    finish = true;
+            }
+        }
+        if (begin_lights) {
+            li = 0, su = sv = 0, total = 0.;
+            need_shadow = true;
+        }
+        if (finish) {
+            // World::shade_hit (world.rs:42-76).  The reference evaluates reflected_color/refracted_color inside
+            // the per-light loop (Q3), i.e. adds them n_lights times: that factor goes into the child's weight.
+            const DMaterial &m = s.materials[s.prims[h_prim].material];
+            color = color + surface * w;
+            next_ray = true;
+            if (remaining > 0) {
+                const bool refl = m.reflectivity != 0.;
+                const bool refr = m.transparency != 0.;
+                double kr = 1., kt = 1.;
+                if (m.reflectivity > 0. && m.transparency > 0.) {
+                    const double r = schlick(h_n1, h_n2, h_eye, h_normal);
+                    CNT(ST_SCHLICK, 1);
+                    kr = r;
+                    kt = 1. - r;
+                }
+                if (refr) {
+                    // refracted_color, world.rs:108-147
+                    const double n_ratio = h_n1 / h_n2;
+                    const double cos_i = dot(h_eye, h_normal);
+                    const double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+                    CNT(ST_REFRACT, 1);
+                    if (!(sin2_t > 1.)) {
+                        const double cos_t = sqrt(1. - sin2_t);
+                        Pending q;
+                        q.o = h_point - h_normal * RTC_EPS;  // under_point
+                        q.d = h_normal * (n_ratio * cos_i - cos_t) - h_eye * n_ratio;
+                        q.w = w * (nl * (m.transparency * kt));
+                        q.mult = mult * nl;
+                        q.remaining = remaining;  // Q2: not decremented (world.rs:142)
+                        if (sp < RTC_MAX_DEPTH_STACK) {
+                            pend[sp] = q;
+                            sp++;
                         } else {
-                            // the hit primitive enters and becomes the last container
-                            n1 = ri_other;
-                            n2 = ri_hit;
+                            CNT(ST_OVERFLOW, 1);
                         }
                     }
-                    if (m.reflectivity > 0. && m.transparency > 0.) {
-                        const double r = schlick(n1, n2, eye, normal);
-                        cx.count(ST_SCHLICK);
-                        kr = r;
-                        kt = 1. - r;
-                    }
-                    if (refr) {
-                        // world.rs:116-142
-                        const double n_ratio = n1 / n2;
-                        const double cos_i = dot(eye, normal);
-                        const double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
-                        cx.count(ST_REFRACT);
-                        if (!(sin2_t > 1.)) {
-                            const double cos_t = sqrt(1. - sin2_t);
-                            Pending q;
-                            q.o = under;
-                            q.d = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
-                            q.w = w * (nl * (m.transparency * kt));
-                            q.mult = mult * nl;
-                            q.remaining = remaining;  // Q2: not decremented (world.rs:142)
-                            if (sp < RTC_MAX_DEPTH_STACK) {
-                                pend[sp] = q;
-                                sp++;
-                            } else {
-                                cx.count(ST_OVERFLOW);
-                            }
-                        }
-                    }
-                    if (refl) {
-                        // world.rs:103-105
-                        ray.o = over;
-                        ray.d = reflectv;
-                        w = w * (nl * (m.reflectivity * kr));
-                        mult = mult * nl;
-                        remaining -= 1;
-                        follow = true;
-                    }
+                }
+                if (refl) {
+                    // reflected_color, world.rs:93-106
+                    const V3 d_in = -h_eye;
+                    ray.o = h_point + h_normal * RTC_EPS;  // over_point
+                    ray.d = reflect(d_in, h_normal);
+                    w = w * (nl * (m.reflectivity * kr));
+                    mult = mult * nl;
+                    remaining -= 1;
+                    next_ray = false;
+                    mode = MODE_CLOSEST;
+                    best.t = inf, best.prim = -1;
+                    CNT(ST_SECONDARY, 1);
+                    CNT(ST_SECONDARY_REF, mult);
+                    rays++;
                 }
             }
-            if (!follow) {
-                if (sp == 0) break;
+        }
+        if (next_ray) {
+            if (sp == 0) {
+                alive = false;
+            } else {
                 sp--;
                 const Pending q = pend[sp];
                 ray.o = q.o, ray.d = q.d, w = q.w, mult = q.mult, remaining = q.remaining;
+                mode = MODE_CLOSEST;
+                best.t = inf, best.prim = -1;
+                CNT(ST_SECONDARY, 1);
+                CNT(ST_SECONDARY_REF, mult);
+                rays++;
             }
-            cx.count(ST_SECONDARY);
-            if (STATS) cnt.c[ST_SECONDARY_REF] += (unsigned long long)mult;
+        }
+        if (need_shadow) {
+            const DLight &lt = s.lights[li];
+            V3 lp = ld3(lt.position);
+            if (lt.is_area)  // AreaLight::point_on_light, light.rs:106-108
+                lp = ld3(lt.corner) + ld3(lt.uvec) * ((double)su + 0.5) + ld3(lt.vvec) * ((double)sv + 0.5);
+            const V3 over = h_point + h_normal * RTC_EPS;
+            const V3 dv = lp - over;  // world.rs:79-83
+            ray.o = over;
+            ray.d = normalize(dv);
+            best.t = magnitude(dv);
+            best.prim = -1;
+            mode = MODE_SHADOW;
+            CNT(ST_SHADOW, 1);
+        }
+        if (rays > RTC_MAX_RAYS_PER_PIXEL) {
+            CNT(ST_OVERFLOW, 1);
+            color = mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.);
+            alive = false;
         }
     }
+
     if (in_image) {
         double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
         px[0] = color.x, px[1] = color.y, px[2] = color.z;

@@ -457,6 +457,8 @@ struct Builder {
 void Scene::build_bvh() {
     bvh.clear(), bvh_prims.clear();
     bvh_max_depth = 0, bvh_max_leaf = 0;
+    root_ref = 0;
+    for (int k = 0; k < 3; k++) root_min[k] = root_max[k] = 0.0;
     std::vector<int32_t> order;
     for (size_t i = 0; i < prims.size(); i++)
         if (prim_bounded[i]) order.push_back((int32_t)i);
@@ -475,36 +477,49 @@ void Scene::build_bvh() {
     }
     bvh_max_depth = b.max_depth;
 
-    // breadth-first relayout, the two children of a node adjacent (right = left + 1)
-    std::vector<int> queue{0};
-    std::vector<int> new_index(b.nodes.size(), -1);
-    new_index[0] = 0;
-    bvh.resize(1);
-    size_t head = 0;
-    while (head < queue.size()) {
-        const int t = queue[head++];
-        const BuildNode &n = b.nodes[t];
-        DBvhNode d{};
-        for (int k = 0; k < 3; k++) d.bmin[k] = n.b.lo[k], d.bmax[k] = n.b.hi[k];
-        if (n.left < 0) {
-            d.left = n.first;
-            d.count = n.count;
-            bvh_max_leaf = std::max<uint32_t>(bvh_max_leaf, (uint32_t)n.count);
-        } else {
-            const int li = (int)bvh.size();
-            bvh.resize(bvh.size() + 2);
-            new_index[n.left] = li, new_index[n.right] = li + 1;
-            queue.push_back(n.left), queue.push_back(n.right);
-            d.left = li;
-            d.count = 0;
+    // Breadth-first relayout of the INTERNAL nodes only; every node stores both children's boxes.
+    // Leaves become child references ~((first << 3) | (count - 1)), `first` relative to prim_list.
+    const int32_t base = (int32_t)unbounded.size();
+    auto leaf_ref = [&](const BuildNode &n) -> int32_t {
+        bvh_max_leaf = std::max<uint32_t>(bvh_max_leaf, (uint32_t)n.count);
+        return ~(((base + n.first) << 3) | (n.count - 1));
+    };
+    for (int k = 0; k < 3; k++) root_min[k] = b.nodes[0].b.lo[k], root_max[k] = b.nodes[0].b.hi[k];
+    if (b.nodes[0].left < 0) {
+        root_ref = leaf_ref(b.nodes[0]);
+    } else {
+        root_ref = 0;
+        std::vector<int> queue{0};
+        std::vector<int> new_index(b.nodes.size(), -1);
+        new_index[0] = 0;
+        int next = 1;
+        // first pass: assign indices in BFS order
+        for (size_t head = 0; head < queue.size(); head++) {
+            const BuildNode &n = b.nodes[queue[head]];
+            for (int c : {n.left, n.right})
+                if (b.nodes[c].left >= 0) {
+                    new_index[c] = next++;
+                    queue.push_back(c);
+                }
         }
-        bvh[new_index[t]] = d;
+        bvh.resize(next);
+        for (int t : queue) {
+            const BuildNode &n = b.nodes[t];
+            const BuildNode &l = b.nodes[n.left], &r = b.nodes[n.right];
+            DBvhNode d{};
+            for (int k = 0; k < 3; k++) {
+                d.lmin[k] = l.b.lo[k], d.lmax[k] = l.b.hi[k];
+                d.rmin[k] = r.b.lo[k], d.rmax[k] = r.b.hi[k];
+            }
+            d.left = (l.left >= 0) ? new_index[n.left] : leaf_ref(l);
+            d.right = (r.left >= 0) ? new_index[n.right] : leaf_ref(r);
+            bvh[new_index[t]] = d;
+        }
     }
     bvh_prims = order;
-    // Leaf primitives in ascending flattened index: with equal t the lower index wins anyway, but a sorted leaf
-    // lets the kernel keep the cheap strict-less test inside a leaf.
-    for (DBvhNode &n : bvh)
-        if (n.count > 0) std::sort(bvh_prims.begin() + n.left, bvh_prims.begin() + n.left + n.count);
+    // Leaf primitives in ascending flattened index (deterministic visiting order inside a leaf).
+    for (const BuildNode &n : b.nodes)
+        if (n.left < 0) std::sort(bvh_prims.begin() + n.first, bvh_prims.begin() + n.first + n.count);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -563,8 +578,17 @@ int Scene::upload(int dev) {
     if ((rc = upload_vec(*this, lights, dscene.lights))) return rc;
     if ((rc = upload_vec(*this, dpatterns, dscene.patterns))) return rc;
     if ((rc = upload_vec(*this, bvh, dscene.bvh))) return rc;
-    if ((rc = upload_vec(*this, bvh_prims, dscene.bvh_prims))) return rc;
-    if ((rc = upload_vec(*this, unbounded, dscene.unbounded))) return rc;
+    {
+        std::vector<int32_t> list(unbounded);
+        list.insert(list.end(), bvh_prims.begin(), bvh_prims.end());
+        if ((rc = upload_vec(*this, list, dscene.prim_list))) return rc;
+        std::vector<int32_t> all(prims.size());
+        for (size_t i = 0; i < all.size(); i++) all[i] = (int32_t)i;
+        if ((rc = upload_vec(*this, all, dscene.all_list))) return rc;
+    }
+    for (int k = 0; k < 3; k++) dscene.root_min[k] = root_min[k], dscene.root_max[k] = root_max[k];
+    dscene.root_ref = root_ref;
+    dscene.n_bounded = (int32_t)bvh_prims.size();
     dscene.n_prims = (int32_t)prims.size();
     dscene.n_unbounded = (int32_t)unbounded.size();
     dscene.n_bvh_nodes = (int32_t)bvh.size();

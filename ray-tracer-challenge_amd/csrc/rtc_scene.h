@@ -70,6 +70,8 @@ struct Scene {
     std::vector<Bounds> prim_bounds;  // world-space, padded; only meaningful for bounded prims
     std::vector<uint8_t> prim_bounded;
     uint32_t bvh_max_depth = 0, bvh_max_leaf = 0;
+    int32_t root_ref = 0;
+    double root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 
     // ---- device state ----
     DScene dscene{};

@@ -6,8 +6,9 @@
 //   DPrim[]     one per leaf shape in depth-first (== reference traversal) order, 56 B
 //   DTri[]      triangle payloads (p1, e1, e2, n1..n3), 144 B
 //   DMaterial[] 88 B, DLight[] 136 B, DPattern[] 160 B
-//   DBvhNode[]  64 B binary BVH nodes over the bounded primitives (breadth-first order)
-//   int bvh_prims[] leaf -> primitive index; int unbounded[] primitives tested for every ray
+//   DBvhNode[]  128 B internal nodes of the binary BVH over the bounded primitives (breadth-first order),
+//               each holding BOTH children's boxes
+//   int prim_list[] unbounded primitives (tested for every ray) followed by the BVH leaves' primitive runs
 #pragma once
 #include <stdint.h>
 
@@ -67,11 +68,15 @@ struct DPattern {
     double inv[12];
 };
 
+// One per INTERNAL node of the binary BVH (128 B = one cache line pair): both children's padded world-space
+// boxes live in the parent so a traversal step costs a single fetch.  Child references: >= 0 is the index
+// of another internal node; < 0 encodes a leaf as ~((first << 3) | (count - 1)) with `first` an offset into
+// DScene::prim_list.
 struct DBvhNode {
-    double bmin[3];
-    double bmax[3];
-    int32_t left;   // internal: index of the left child (right = left + 1); leaf: first index into bvh_prims
-    int32_t count;  // 0 = internal, > 0 = leaf primitive count
+    double lmin[3], lmax[3];
+    double rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad[6];
 };
 
 struct DCamera {
@@ -91,9 +96,11 @@ struct DScene {
     const DLight *lights;
     const DPattern *patterns;
     const DBvhNode *bvh;
-    const int32_t *bvh_prims;
-    const int32_t *unbounded;
-    int32_t n_prims, n_unbounded, n_bvh_nodes, n_lights, n_materials;
+    const int32_t *prim_list;  // [0, n_unbounded): primitives tested for every ray; then the BVH leaves' runs
+    const int32_t *all_list;   // identity 0..n_prims-1 (brute-force mode)
+    double root_min[3], root_max[3];
+    int32_t root_ref;          // child reference of the BVH root (valid when n_bounded > 0)
+    int32_t n_prims, n_unbounded, n_bounded, n_bvh_nodes, n_lights, n_materials;
     int32_t all_cast_shadow;  // 1 if every material has casts_shadow: shadow rays may stop at any hit
     int32_t any_pattern;
     int32_t pad;
