@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtc_amd.so")
+LIB_PATH = os.environ.get("RTC_AMD_LIB") or os.path.join(_HERE, "librtc_amd.so")  # override: A/B builds only
 
 OK, ERR_NON_INVERTIBLE, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_IO, ERR_PARSE, ERR_OVERFLOW = range(9)
 SPHERE, PLANE, CUBE, CYLINDER, CONE = range(5)

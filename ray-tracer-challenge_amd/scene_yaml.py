@@ -269,10 +269,16 @@ def _construct_object(d, definitions, base_dir):
         children = d["children"]
         if not isinstance(children, list):
             raise ParseError("Invalid parameters for group: Group 'children' must be a sequence")
+        nested, others = [], []
         for c in children:
             if not isinstance(c, dict):
                 raise ParseError("Invalid parameters for group: Each value in a group's 'children' must be a mapping")
-            g.children.append(_construct_object(c, definitions, base_dir))
+            child = _construct_object(c, definitions, base_dir)
+            # A nested YAML group is added to its parent as soon as it is constructed (lib.rs:677-679); every
+            # other child only after the whole `children` list has been built (lib.rs:707-712): nested groups
+            # therefore come first in Group::children order.
+            (nested if c.get("add") == "group" else others).append(child)
+        g.children = nested + others
         return g
     if kind == "obj":
         fn = d.get("file")
