@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--workload", default="teapot_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-stride", type=int, default=0, help="0 = choose for ~10-20 s of CPU work")
+    ap.add_argument("--use-bvh", type=int, default=0, help="0 auto, 1 force BVH, 2 force brute force (A/B only)")
     ap.add_argument("--extra", action="store_true", help="also time the other workloads (untimed region, N=1)")
     args = ap.parse_args()
 
@@ -77,6 +78,9 @@ def main():
     scene = cam.compile(world, device=local_rank)
     hsize, vsize = cam.hsize, cam.vsize
     tile = dict(tile_rows=TILE_ROWS, tile_index=rank, tile_count=world_size) if distributed else {}
+    ropts = dict(tile)
+    if args.use_bvh:
+        ropts["use_bvh"] = args.use_bvh
     local_rows = scene.local_rows(**tile) if distributed else vsize
     max_rows = local_rows
     if distributed:
@@ -99,7 +103,7 @@ def main():
         index = torch.from_numpy(idx.reshape(-1)).to(dev)
 
     def step():
-        scene.render_device(buf.data_ptr(), stream.cuda_stream, **tile)
+        scene.render_device(buf.data_ptr(), stream.cuda_stream, **ropts)
         if distributed:
             dist.gather(buf, gather_list, dst=0)
             if rank == 0:
@@ -111,7 +115,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     # ---- counters of one frame (counting kernel variant, outside the timed region) ----
-    scene.render_device(buf.data_ptr(), stream.cuda_stream, collect_stats=True, **tile)
+    scene.render_device(buf.data_ptr(), stream.cuda_stream, collect_stats=True, **ropts)
     st = scene.stats()
     keys = ["primary_rays", "shadow_rays", "secondary_rays", "secondary_rays_reference", "box_tests",
             "shaded_hits", "light_evals", "container_passes", "xform_levels", "overflow"]
@@ -135,7 +139,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record(stream)
-        scene.render_device(buf.data_ptr(), stream.cuda_stream, **tile)
+        scene.render_device(buf.data_ptr(), stream.cuda_stream, **ropts)
         ev[i][1].record(stream)
         if distributed:
             dist.gather(buf, gather_list, dst=0)
@@ -221,16 +225,17 @@ def main():
             w2, c2 = load(wl)
             s2 = c2.compile(w2, device=local_rank)
             b2 = torch.zeros((c2.vsize, c2.hsize, 3), dtype=torch.float64, device=dev)
-            s2.render_device(b2.data_ptr(), stream.cuda_stream, collect_stats=True)
+            kw2 = {"use_bvh": args.use_bvh} if args.use_bvh else {}
+            s2.render_device(b2.data_ptr(), stream.cuda_stream, collect_stats=True, **kw2)
             st2 = s2.stats()
             for _ in range(2):
-                s2.render_device(b2.data_ptr(), stream.cuda_stream)
+                s2.render_device(b2.data_ptr(), stream.cuda_stream, **kw2)
             torch.cuda.synchronize(dev)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 5
             a.record(stream)
             for _ in range(reps):
-                s2.render_device(b2.data_ptr(), stream.cuda_stream)
+                s2.render_device(b2.data_ptr(), stream.cuda_stream, **kw2)
             b.record(stream)
             torch.cuda.synchronize(dev)
             ms = a.elapsed_time(b) / reps

@@ -108,19 +108,85 @@ DEV double min3_total(double a, double b, double c) {  // Iterator::min_by(total
     return m;
 }
 
-// Up to four intersection records of one primitive, in the order the reference pushes them.
-struct Recs {
-    double t0, t1, t2, t3;
-    double u, v;
-    unsigned mask;
+// ---------------------------------------------------------------------------------------------
+// per-lane trace state and the record visitors
+// ---------------------------------------------------------------------------------------------
+
+enum Mode { MODE_CLOSEST = 0, MODE_SHADOW = 1, MODE_CONTAINER = 2 };
+
+// What one pass of the intersection loop accumulates.  The reference materialises and sorts the full
+// intersection list (world.rs:176-186); both consumers of that list are order statistics that can be folded
+// record by record:
+//   hit() (intersection.rs:207-219): smallest t > 0; first record wins on ties within a primitive, the lower
+//     flattened index between primitives (stable order, Q15);
+//   the containers loop (intersection.rs:150-179), streaming form: per primitive, count the records strictly
+//     before the hit and remember the latest of them.  A primitive is "in containers" just before the hit iff
+//     that count is odd, and the list's last element is the open primitive whose last record is latest in the
+//     (stably) sorted order, i.e. max over (last_t, primitive index).
+// Records whose t is NaN fail every comparison below and are dropped (DESIGN.md "NaN records").
+struct Trace {
+    int mode;
+    // MODE_CLOSEST / MODE_SHADOW
+    double best_t;
+    int best_prim;
+    double best_u, best_v;
+    // MODE_CONTAINER
+    double c_thit;
+    int c_hit_prim;
+    double c_best_t;   // latest crossing among OTHER open primitives
+    int c_best_prim;   // -1: none
+    int c_hit_open;    // the hit primitive has an odd number of records before the hit
+    double c_hit_last;
+    // per-primitive scratch of the container pass
+    int n;
+    double last;
 };
 
+DEV void visit(Trace &T, int pi, double t) {
+    if (T.mode == MODE_CONTAINER) {
+        if (t < T.c_thit) {
+            if (T.n == 0 || t >= T.last) T.last = t;
+            T.n++;
+        }
+    } else if (t > 0. && (t < T.best_t || (t == T.best_t && pi < T.best_prim))) {
+        T.best_t = t;
+        T.best_prim = pi;
+    }
+}
+DEV void visit_uv(Trace &T, int pi, double t, double u, double v) {
+    if (T.mode == MODE_CONTAINER) {
+        if (t < T.c_thit) {
+            if (T.n == 0 || t >= T.last) T.last = t;
+            T.n++;
+        }
+    } else if (t > 0. && (t < T.best_t || (t == T.best_t && pi < T.best_prim))) {
+        T.best_t = t;
+        T.best_prim = pi;
+        T.best_u = u;
+        T.best_v = v;
+    }
+}
+DEV void end_prim(Trace &T, int pi) {
+    if (T.mode == MODE_CONTAINER) {
+        if (T.n & 1) {
+            if (pi == T.c_hit_prim) {
+                T.c_hit_open = 1;
+                T.c_hit_last = T.last;
+            } else if (T.c_best_prim < 0 || T.last > T.c_best_t || (T.last == T.c_best_t && pi > T.c_best_prim)) {
+                T.c_best_t = T.last;
+                T.c_best_prim = pi;
+            }
+        }
+        T.n = 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-// local_intersect functions (object-space ray)
+// local_intersect functions (object-space ray); records are visited in the order the reference pushes them
 // ---------------------------------------------------------------------------------------------
 
 // shape.rs:218-239
-DEV void isect_sphere(const Ray &r, Recs &o) {
+DEV void isect_sphere(const Ray &r, Trace &T, int pi) {
     const V3 s2r = r.o - mk(0., 0., 0.);
     const double a = dot(r.d, r.d);
     const double b = 2. * dot(r.d, s2r);
@@ -128,16 +194,8 @@ DEV void isect_sphere(const Ray &r, Recs &o) {
     const double disc = b * b - 4. * a * c;
     if (disc < 0.) return;
     const double sq = sqrt(disc);
-    o.t0 = (-b - sq) / (2. * a);
-    o.t1 = (-b + sq) / (2. * a);
-    o.mask = 3u;
-}
-
-// shape.rs:510-517
-DEV void isect_plane(const Ray &r, Recs &o) {
-    if (fabs(r.d.y) < RTC_EPS) return;
-    o.t0 = -r.o.y / r.d.y;
-    o.mask = 1u;
+    visit(T, pi, (-b - sq) / (2. * a));
+    visit(T, pi, (-b + sq) / (2. * a));
 }
 
 // shape.rs:708-720 (Q9: divides by a zero direction on purpose)
@@ -152,7 +210,7 @@ DEV void cube_axis(double origin, double direction, double &tmin, double &tmax) 
     tmin = a, tmax = b;
 }
 // shape.rs:665-704
-DEV void isect_cube(const Ray &r, Recs &o) {
+DEV void isect_cube(const Ray &r, Trace &T, int pi) {
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double xmin, xmax, ymin, ymax, zmin, zmax;
     cube_axis(r.o.x, r.d.x, xmin, xmax);
@@ -163,8 +221,8 @@ DEV void isect_cube(const Ray &r, Recs &o) {
     const double tmin = max3_total(xmin, ymin, zmin);
     const double tmax = min3_total(xmax, ymax, zmax);
     if (tmin > tmax) return;
-    o.t0 = tmin, o.t1 = tmax;
-    o.mask = 3u;
+    visit(T, pi, tmin);
+    visit(T, pi, tmax);
 }
 
 // intersection.rs:34-39 (Q7: `<= radius`, not radius^2)
@@ -175,10 +233,9 @@ DEV bool check_cap(const Ray &r, double t, double radius) {
 }
 
 // shape.rs:895-959
-DEV void isect_cylinder(const Ray &r, double minimum, double maximum, int closed, Recs &o) {
+DEV void isect_cylinder(const Ray &r, double minimum, double maximum, int closed, Trace &T, int pi) {
     const double a = r.d.x * r.d.x + r.d.z * r.d.z;
-    bool side = !approx_zero(a);
-    if (side) {
+    if (!approx_zero(a)) {
         const double b = 2. * r.o.x * r.d.x + 2. * r.o.z * r.d.z;
         const double c = r.o.x * r.o.x + r.o.z * r.o.z - 1.;
         const double disc = b * b - 4. * a * c;
@@ -192,27 +249,26 @@ DEV void isect_cylinder(const Ray &r, double minimum, double maximum, int closed
             t1 = t;
         }
         const double y0 = r.o.y + t0 * r.d.y;
-        if (minimum < y0 && y0 < maximum) o.t0 = t0, o.mask |= 1u;
+        if (minimum < y0 && y0 < maximum) visit(T, pi, t0);
         const double y1 = r.o.y + t1 * r.d.y;
-        if (minimum < y1 && y1 < maximum) o.t1 = t1, o.mask |= 2u;
+        if (minimum < y1 && y1 < maximum) visit(T, pi, t1);
     }
     // intersect_caps, shape.rs:938-959
     if (!closed || approx_zero(r.d.y)) return;
     double t = (minimum - r.o.y) / r.d.y;
-    if (check_cap(r, t, 1.)) o.t2 = t, o.mask |= 4u;
+    if (check_cap(r, t, 1.)) visit(T, pi, t);
     t = (maximum - r.o.y) / r.d.y;
-    if (check_cap(r, t, 1.)) o.t3 = t, o.mask |= 8u;
+    if (check_cap(r, t, 1.)) visit(T, pi, t);
 }
 
 // shape.rs:1212-1281 (Q8)
-DEV void isect_cone(const Ray &r, double minimum, double maximum, int closed, Recs &o) {
+DEV void isect_cone(const Ray &r, double minimum, double maximum, int closed, Trace &T, int pi) {
     const double a = r.d.x * r.d.x - r.d.y * r.d.y + r.d.z * r.d.z;
     const double b = 2. * r.o.x * r.d.x - 2. * r.o.y * r.d.y + 2. * r.o.z * r.d.z;
     const double c = r.o.x * r.o.x - r.o.y * r.o.y + r.o.z * r.o.z;
     if (approx_zero(a)) {
         if (!closed) {
-            o.t0 = -c / (2. * b);  // no y-range check, no b != 0 check
-            o.mask = 1u;
+            visit(T, pi, -c / (2. * b));  // no y-range check, no b != 0 check
             return;
         }
     } else {
@@ -227,22 +283,22 @@ DEV void isect_cone(const Ray &r, double minimum, double maximum, int closed, Re
             t1 = t;
         }
         const double y0 = r.o.y + t0 * r.d.y;
-        if (minimum < y0 && y0 < maximum) o.t0 = t0, o.mask |= 1u;
+        if (minimum < y0 && y0 < maximum) visit(T, pi, t0);
         const double y1 = r.o.y + t1 * r.d.y;
-        if (minimum < y1 && y1 < maximum) o.t1 = t1, o.mask |= 2u;
+        if (minimum < y1 && y1 < maximum) visit(T, pi, t1);
     }
     // intersect_caps, shape.rs:1260-1281: |min| / |max| for both the plane height and the radius
     if (!closed || approx_zero(r.d.y)) return;
     const double amin = fabs(minimum), amax = fabs(maximum);
     double t = (amin - r.o.y) / r.d.y;
-    if (check_cap(r, t, amin)) o.t2 = t, o.mask |= 4u;
+    if (check_cap(r, t, amin)) visit(T, pi, t);
     t = (amax - r.o.y) / r.d.y;
-    if (check_cap(r, t, amax)) o.t3 = t, o.mask |= 8u;
+    if (check_cap(r, t, amax)) visit(T, pi, t);
 }
 
-// shape.rs:1479-1502 == 1712-1735
-DEV void isect_triangle(const Ray &r, const DTri &tr, Recs &o) {
-    const V3 e1 = ld3(tr.e1), e2 = ld3(tr.e2), p1 = ld3(tr.p1);
+// shape.rs:1479-1502 == 1712-1735; a = p1, e1, e2
+DEV void isect_triangle(const Ray &r, const double *a, Trace &T, int pi) {
+    const V3 p1 = ld3(a), e1 = ld3(a + 3), e2 = ld3(a + 6);
     const V3 dce2 = cross(r.d, e2);
     const double det = dot(e1, dce2);
     if (fabs(det) < RTC_EPS) return;
@@ -253,9 +309,50 @@ DEV void isect_triangle(const Ray &r, const DTri &tr, Recs &o) {
     const V3 oce1 = cross(p1o, e1);
     const double v = f * dot(r.d, oce1);
     if (v < 0. || (u + v) > 1.) return;
-    o.t0 = f * dot(e2, oce1);
-    o.u = u, o.v = v;
-    o.mask = 1u;
+    visit_uv(T, pi, f * dot(e2, oce1), u, v);
+}
+
+// One primitive against the ray `r` given in the space of the primitive's parent (world space for top-level
+// shapes): Shape::intersect = ray.transform(inverse(T_own)) + local_intersect (e.g. shape.rs:254-258).  A plane
+// only ever reads the y components of the object-space ray, so only row 1 of the product is formed (the
+// arithmetic of that row is unchanged).
+DEV void isect_leaf(const DLeaf &L, const Ray &r, Trace &T) {
+    const int pi = L.prim;
+    const double *m = L.a;
+    switch (L.type) {
+    case PT_PLANE: {  // shape.rs:510-517
+        const double oy = m[4] * r.o.x + m[5] * r.o.y + m[6] * r.o.z + m[7];
+        const double dy = m[4] * r.d.x + m[5] * r.d.y + m[6] * r.d.z;
+        if (!(fabs(dy) < RTC_EPS)) visit(T, pi, -oy / dy);
+        break;
+    }
+    case PT_SPHERE: {
+        Ray q;
+        q.o = xf_point(m, r.o), q.d = xf_vector(m, r.d);
+        isect_sphere(q, T, pi);
+        break;
+    }
+    case PT_CUBE: {
+        Ray q;
+        q.o = xf_point(m, r.o), q.d = xf_vector(m, r.d);
+        isect_cube(q, T, pi);
+        break;
+    }
+    case PT_CYLINDER: {
+        Ray q;
+        q.o = xf_point(m, r.o), q.d = xf_vector(m, r.d);
+        isect_cylinder(q, L.minimum, L.maximum, L.closed, T, pi);
+        break;
+    }
+    case PT_CONE: {
+        Ray q;
+        q.o = xf_point(m, r.o), q.d = xf_vector(m, r.d);
+        isect_cone(q, L.minimum, L.maximum, L.closed, T, pi);
+        break;
+    }
+    default: isect_triangle(r, m, T, pi); break;
+    }
+    end_prim(T, pi);
 }
 
 // Rust's `%` on f64 is fmod; pattern.rs kinds
@@ -364,66 +461,8 @@ DEV double schlick(double n1, double n2, V3 eye, V3 normal) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-lane helpers
+// BVH helpers
 // ---------------------------------------------------------------------------------------------
-
-struct Hit {
-    double t;
-    int prim;
-    double u, v;
-};
-
-// hit() over this primitive's records (intersection.rs:207-219): smallest t > 0, first record wins on ties;
-// between primitives the lower flattened index wins (stable order, Q15).
-DEV void closest_visit(Hit &best, int pi, const Recs &rc) {
-#define RTC_TRY(bit, tt)                                                                      \
-    if ((rc.mask & (bit)) && (tt) > 0. && ((tt) < best.t || ((tt) == best.t && pi < best.prim))) { \
-        best.t = (tt);                                                                        \
-        best.prim = pi;                                                                       \
-        best.u = rc.u;                                                                        \
-        best.v = rc.v;                                                                        \
-    }
-    RTC_TRY(1u, rc.t0)
-    RTC_TRY(2u, rc.t1)
-    RTC_TRY(4u, rc.t2)
-    RTC_TRY(8u, rc.t3)
-#undef RTC_TRY
-}
-
-// Streaming form of the containers loop (intersection.rs:150-179).  For one primitive: count the records
-// strictly before the hit and remember the latest of them.  A primitive is "in containers" just before the
-// hit iff that count is odd, and the list's last element is the open primitive whose last record is latest
-// in the (stably) sorted order, i.e. max over (last_t, primitive index).
-struct Containers {
-    double t_hit;
-    int hit_prim;
-    double best_t;   // latest crossing among OTHER open primitives
-    int best_prim;   // -1: none
-    int hit_open;    // hit primitive has an odd number of records before the hit
-    double hit_last;
-};
-DEV void container_visit(Containers &c, int pi, const Recs &rc) {
-    int n = 0;
-    double last = 0.;
-#define RTC_CNT(bit, tt)                          \
-    if ((rc.mask & (bit)) && (tt) < c.t_hit) {    \
-        if (n == 0 || (tt) >= last) last = (tt);  \
-        n++;                                      \
-    }
-    RTC_CNT(1u, rc.t0)
-    RTC_CNT(2u, rc.t1)
-    RTC_CNT(4u, rc.t2)
-    RTC_CNT(8u, rc.t3)
-#undef RTC_CNT
-    if (!(n & 1)) return;
-    if (pi == c.hit_prim) {
-        c.hit_open = 1;
-        c.hit_last = last;
-    } else if (c.best_prim < 0 || last > c.best_t || (last == c.best_t && pi > c.best_prim)) {
-        c.best_t = last;
-        c.best_prim = pi;
-    }
-}
 
 // Slab test of a padded world-space box.  This is the build's own culling arithmetic, not reference
 // arithmetic: it uses FMA and an approximate reciprocal; the 1e-6 relative padding of the boxes (host) is ten
@@ -455,8 +494,6 @@ struct Pending {
     int remaining;
 };
 
-enum Mode { MODE_CLOSEST = 0, MODE_SHADOW = 1, MODE_CONTAINER = 2 };
-
 // canvas row of this rank's local row l (interleaved row tiles)
 DEV unsigned canvas_row(const DRenderParams &p, unsigned l) {
     if (p.tile_count <= 1) return l;
@@ -469,11 +506,28 @@ DEV unsigned canvas_row(const DRenderParams &p, unsigned l) {
         if (STATS) cnt.c[idx] += (unsigned long long)(n); \
     } while (0)
 
-// The megakernel.  Per lane it is a small state machine around ONE copy of the intersection loop:
+// Ray::transform through a run of ancestor (group) inverses, root first (shape.rs:2035)
+DEV Ray through_ancestors(const DScene &s, int off, int len, Ray r) {
+    for (int k = 0; k < len; k++) {
+        const double *m = s.xforms[s.chains[off + k]].inv;
+        Ray q;
+        q.o = xf_point(m, r.o);
+        q.d = xf_vector(m, r.d);
+        r = q;
+    }
+    return r;
+}
+
+// The megakernel.  Per lane it is a small state machine around ONE intersection pass:
 //   MODE_CLOSEST   World::color_at's closest hit for a primary / reflect / refract ray
 //   MODE_CONTAINER second pass over the same ray for n1/n2 (only for transparent hits)
 //   MODE_SHADOW    World::is_shadowed for one light sample
-// so lanes tracing different kinds of rays still execute the same instructions.
+// so lanes tracing different kinds of rays still execute the same instructions.  A pass has two phases:
+//   1. the always-tested list (unbounded primitives, or every primitive in brute-force mode): every lane
+//      walks it in lockstep, so the records come through the scalar cache into SGPRs and the per-type
+//      switch is a scalar branch;
+//   2. ordered traversal of the binary BVH with the per-lane stack in LDS; leaf records come through the
+//      vector cache, one 144-byte record per test.
 template <bool STATS>
 __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DRenderParams prm,
                                                                      double *__restrict__ out,
@@ -507,11 +561,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     // ---- current ray ----
     Ray ray;
     ray.o = ray.d = mk(0., 0., 0.);
-    int mode = MODE_CLOSEST;
-    Hit best;
-    best.t = inf, best.prim = -1, best.u = best.v = 0.;
-    Containers cont;
-    cont.t_hit = 0., cont.hit_prim = -1, cont.best_t = 0., cont.best_prim = -1, cont.hit_open = 0, cont.hit_last = 0.;
+    Trace T;
+    T.mode = MODE_CLOSEST;
+    T.best_t = inf, T.best_prim = -1, T.best_u = T.best_v = 0.;
+    T.c_thit = 0., T.c_hit_prim = -1, T.c_best_t = 0., T.c_best_prim = -1, T.c_hit_open = 0, T.c_hit_last = 0.;
+    T.n = 0, T.last = 0.;
     // ---- shading context (valid from the closest hit until the last shadow ray of that hit) ----
     int h_prim = -1;
     V3 h_point = mk(0., 0., 0.), h_eye = mk(0., 0., 0.), h_normal = mk(0., 0., 0.);
@@ -534,73 +588,63 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         rays = 1;
     }
 
+    const DLeaf *__restrict__ const lin = use_bvh ? s.leaves : s.leaves_all;
+    const int n_lin = use_bvh ? s.n_unbounded : s.n_prims;
+
     while (alive) {
         // =====================================================================================
-        // World::intersect (world.rs:176-186) without materialising the list: linear run over the
-        // unbounded primitives, then ordered BVH traversal; one inlined copy serves all three modes.
+        // World::intersect (world.rs:176-186) without materialising the list
         // =====================================================================================
+        const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
+        int cache_id = -1;    // ancestor chain the cached ray is expressed in
+        Ray cache_ray = ray;
         {
-            const int32_t *__restrict__ list = use_bvh ? s.prim_list : s.all_list;
-            int pos = 0, end = use_bvh ? s.n_unbounded : s.n_prims;
-            bool root_pending = use_bvh && s.n_bounded > 0;
-            int sb = 0;
-            const double lo = (mode == MODE_CONTAINER) ? -inf : 0.;
-            const bool any_hit = (mode == MODE_SHADOW) && s.all_cast_shadow;
-            V3 inv_d = mk(0., 0., 0.), oi = mk(0., 0., 0.);
-            if (root_pending) {
-                inv_d = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
-                oi = mk(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z);
+            // ---- phase 1: lockstep walk over the always-tested list (i, L.* are wave-uniform) ----
+            int u_cache = -1;
+            for (int i = 0; i < n_lin; i++) {
+                const DLeaf &L = lin[i];
+                Ray r = ray;
+                if (L.anc_len > 0) {
+                    if (L.anc_id != u_cache) {
+                        cache_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
+                        u_cache = L.anc_id;
+                        CNT(ST_XFORM, L.anc_len);  // Group::intersect transforms the ray once per group
+                    }
+                    r = cache_ray;
+                }
+                if (!(any_hit && T.best_prim >= 0)) {
+                    CNT(ST_XFORM, L.type < PT_TRIANGLE ? 1 : 0);  // the shape's own Ray::transform
+                    CNT(ST_PRIM0 + L.type, 1);
+                    isect_leaf(L, r, T);
+                }
             }
-            int cache_chain = -1;
-            Ray cache_ray = ray;
+            cache_id = u_cache;
+        }
+        if (use_bvh && s.n_bounded > 0 && !(any_hit && T.best_prim >= 0)) {
+            // ---- phase 2: ordered BVH traversal, leaves tested as they are reached ----
+            const double lo = (T.mode == MODE_CONTAINER) ? -inf : 0.;
+            const V3 inv_d = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
+            const V3 oi = mk(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z);
+            int pos = 0, end = 0, sb = 0;
+            bool root_pending = true;
             for (;;) {
                 if (pos < end) {
-                    const int pi = list[pos++];
-                    const DPrim &p = s.prims[pi];
-                    // Ray::transform down the parent chain, root first (shape.rs:2035, then :256 etc.).
-                    // Triangles of one mesh share their chain: the object-space ray is cached per lane.
+                    const DLeaf &L = s.leaves[pos++];
+                    // Ray::transform down the ancestor chain, root first (shape.rs:2035).  Primitives of one
+                    // group share it: the ray in group space is cached per lane.
                     Ray r = ray;
-                    if (p.chain_len > 0) {
-                        const bool shared = p.type >= PT_TRIANGLE;
-                        if (shared && p.chain_id == cache_chain) {
-                            r = cache_ray;
-                        } else {
-                            for (int k = 0; k < p.chain_len; k++) {
-                                const double *m = s.xforms[s.chains[p.chain_off + k]].inv;
-                                Ray q;
-                                q.o = xf_point(m, r.o);
-                                q.d = xf_vector(m, r.d);
-                                r = q;
-                            }
-                            CNT(ST_XFORM, p.chain_len);
-                            if (shared) cache_chain = p.chain_id, cache_ray = r;
+                    if (L.anc_len > 0) {
+                        if (L.anc_id != cache_id) {
+                            cache_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
+                            cache_id = L.anc_id;
+                            CNT(ST_XFORM, L.anc_len);
                         }
+                        r = cache_ray;
                     }
-                    CNT(ST_PRIM0 + p.type, 1);
-                    Recs rc;
-                    rc.t0 = rc.t1 = rc.t2 = rc.t3 = 0.;
-                    rc.u = rc.v = 0.;
-                    rc.mask = 0u;
-                    switch (p.type) {
-                    case PT_SPHERE: isect_sphere(r, rc); break;
-                    case PT_PLANE: isect_plane(r, rc); break;
-                    case PT_CUBE: isect_cube(r, rc); break;
-                    case PT_CYLINDER: isect_cylinder(r, p.minimum, p.maximum, p.closed, rc); break;
-                    case PT_CONE: isect_cone(r, p.minimum, p.maximum, p.closed, rc); break;
-                    default: isect_triangle(r, s.tris[p.tri], rc); break;
-                    }
-                    // records whose t is NaN can never be the hit (intersection.rs:211-214); dropped
-                    // (DESIGN.md "NaN records")
-                    if (rc.t0 != rc.t0) rc.mask &= ~1u;
-                    if (rc.t1 != rc.t1) rc.mask &= ~2u;
-                    if (rc.t2 != rc.t2) rc.mask &= ~4u;
-                    if (rc.t3 != rc.t3) rc.mask &= ~8u;
-                    if (mode == MODE_CONTAINER) {
-                        container_visit(cont, pi, rc);
-                    } else {
-                        closest_visit(best, pi, rc);
-                        if (any_hit && best.prim >= 0) break;
-                    }
+                    CNT(ST_XFORM, L.type < PT_TRIANGLE ? 1 : 0);
+                    CNT(ST_PRIM0 + L.type, 1);
+                    isect_leaf(L, r, T);
+                    if (any_hit && T.best_prim >= 0) break;
                     continue;
                 }
                 // ---- next leaf ----
@@ -609,7 +653,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     root_pending = false;
                     double tn;
                     CNT(ST_BOX, 1);
-                    if (!slab(s.root_min, s.root_max, inv_d, oi, lo, (mode == MODE_CONTAINER) ? cont.t_hit : best.t, tn))
+                    if (!slab(s.root_min, s.root_max, inv_d, oi, lo, (T.mode == MODE_CONTAINER) ? T.c_thit : T.best_t,
+                              tn))
                         break;
                     ref = s.root_ref;
                 } else if (sb > 0) {
@@ -621,7 +666,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 bool finished = false;
                 while (ref >= 0) {
                     const DBvhNode &n = s.bvh[ref];
-                    const double hi = (mode == MODE_CONTAINER) ? cont.t_hit : best.t;
+                    const double hi = (T.mode == MODE_CONTAINER) ? T.c_thit : T.best_t;
                     double tl, tr;
                     CNT(ST_BOX, 2);
                     const bool hl = slab(n.lmin, n.lmax, inv_d, oi, lo, hi, tl);
@@ -654,16 +699,16 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         // state machine
         // =====================================================================================
         bool begin_lights = false, finish = false, next_ray = false, need_shadow = false;
-        if (mode == MODE_CLOSEST) {
+        if (T.mode == MODE_CLOSEST) {
             // World::color_at, world.rs:30-38
-            if (best.prim < 0 || s.n_lights == 0) {
+            if (T.best_prim < 0 || s.n_lights == 0) {
                 next_ray = true;
             } else {
-                const DPrim &p = s.prims[best.prim];
+                const DPrim &p = s.prims[T.best_prim];
                 const DMaterial &m = s.materials[p.material];
                 // Intersection::prepare_computations, intersection.rs:123-148
-                h_prim = best.prim;
-                h_point = ray.o + ray.d * best.t;
+                h_prim = T.best_prim;
+                h_point = ray.o + ray.d * T.best_t;
                 h_eye = -ray.d;
                 // Shape::normal_at (shape.rs:43-47): world_to_object down the chain (shape.rs:82-90), local
                 // normal, normal_to_world back up with a normalisation per level (shape.rs:94-103).
@@ -673,7 +718,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     if (p.type == PT_TRIANGLE)
                         n = ld3(tr.n1);  // shape.rs:1516-1518
                     else                 // shape.rs:1749-1754
-                        n = ld3(tr.n2) * best.u + ld3(tr.n3) * best.v + ld3(tr.n1) * (1. - best.u - best.v);
+                        n = ld3(tr.n2) * T.best_u + ld3(tr.n3) * T.best_v + ld3(tr.n1) * (1. - T.best_u - T.best_v);
                     // the triangle's own transformation() is the identity (shape.rs:1550-1552): only that
                     // level's normalisation remains
                     n = normalize(n);
@@ -721,22 +766,22 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 CNT(ST_SHADED, 1);
                 if (remaining > 0 && m.transparency != 0.) {
                     // containers loop (intersection.rs:150-179) in streaming form: second pass over the same ray
-                    cont.t_hit = best.t, cont.hit_prim = best.prim;
-                    cont.best_t = 0., cont.best_prim = -1, cont.hit_open = 0, cont.hit_last = 0.;
-                    mode = MODE_CONTAINER;
+                    T.c_thit = T.best_t, T.c_hit_prim = T.best_prim;
+                    T.c_best_t = 0., T.c_best_prim = -1, T.c_hit_open = 0, T.c_hit_last = 0.;
+                    T.mode = MODE_CONTAINER;
                     CNT(ST_CONTAINER, 1);
                     continue;
                 }
                 begin_lights = true;
             }
-        } else if (mode == MODE_CONTAINER) {
+        } else if (T.mode == MODE_CONTAINER) {
             const double ri_hit = s.materials[s.prims[h_prim].material].refractive_index;
             const double ri_other =
-                (cont.best_prim >= 0) ? s.materials[s.prims[cont.best_prim].material].refractive_index : 1.;
-            if (cont.hit_open) {
+                (T.c_best_prim >= 0) ? s.materials[s.prims[T.c_best_prim].material].refractive_index : 1.;
+            if (T.c_hit_open) {
                 // the hit primitive leaves: n1 = last of (others + hit), n2 = last of the others
-                const bool hit_is_last = cont.best_prim < 0 || cont.hit_last > cont.best_t ||
-                                         (cont.hit_last == cont.best_t && h_prim > cont.best_prim);
+                const bool hit_is_last = T.c_best_prim < 0 || T.c_hit_last > T.c_best_t ||
+                                         (T.c_hit_last == T.c_best_t && h_prim > T.c_best_prim);
                 h_n1 = hit_is_last ? ri_hit : ri_other;
                 h_n2 = ri_other;
             } else {
@@ -749,7 +794,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             // World::is_shadowed (world.rs:78-91): only the NEAREST positive hit is consulted (Q5); when every
             // material casts shadows that equals "some hit has 0 < t < distance" (any-hit early exit).
             const bool shadowed =
-                best.prim >= 0 && (s.all_cast_shadow || s.materials[s.prims[best.prim].material].casts_shadow != 0);
+                T.best_prim >= 0 && (s.all_cast_shadow || s.materials[s.prims[T.best_prim].material].casts_shadow != 0);
             const DLight &lt = s.lights[li];
             bool have = true;
             double inten;
@@ -833,8 +878,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     mult = mult * nl;
                     remaining -= 1;
                     next_ray = false;
-                    mode = MODE_CLOSEST;
-                    best.t = inf, best.prim = -1;
+                    T.mode = MODE_CLOSEST;
+                    T.best_t = inf, T.best_prim = -1;
                     CNT(ST_SECONDARY, 1);
                     CNT(ST_SECONDARY_REF, mult);
                     rays++;
@@ -848,8 +893,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 sp--;
                 const Pending q = pend[sp];
                 ray.o = q.o, ray.d = q.d, w = q.w, mult = q.mult, remaining = q.remaining;
-                mode = MODE_CLOSEST;
-                best.t = inf, best.prim = -1;
+                T.mode = MODE_CLOSEST;
+                T.best_t = inf, T.best_prim = -1;
                 CNT(ST_SECONDARY, 1);
                 CNT(ST_SECONDARY_REF, mult);
                 rays++;
@@ -864,9 +909,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             const V3 dv = lp - over;  // world.rs:79-83
             ray.o = over;
             ray.d = normalize(dv);
-            best.t = magnitude(dv);
-            best.prim = -1;
-            mode = MODE_SHADOW;
+            T.best_t = magnitude(dv);
+            T.best_prim = -1;
+            T.mode = MODE_SHADOW;
             CNT(ST_SHADOW, 1);
         }
         if (rays > RTC_MAX_RAYS_PER_PIXEL) {

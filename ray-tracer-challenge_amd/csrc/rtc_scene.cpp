@@ -123,6 +123,7 @@ static void bounds_pad(Bounds &b) {
 int Scene::flatten() {
     xforms.clear(), xform_fwd.clear(), chains.clear(), prims.clear(), tris.clear();
     prim_bounds.clear(), prim_bounded.clear(), unbounded.clear(), bvh.clear(), bvh_prims.clear();
+    prim_anc_id.clear();
     dmaterials.clear(), dpatterns.clear();
 
     if (!has_camera) {
@@ -260,6 +261,7 @@ int Scene::flatten() {
             const bool bounded = local_bounds(it, lb);
             if (bounded) world_bounds(lb, p.chain_off, p.chain_len, wb);
             prims.push_back(p);
+            prim_anc_id.push_back(f.chain_len > 0 ? f.chain_id : -1);
             prim_bounds.push_back(wb);
             prim_bounded.push_back(bounded ? 1 : 0);
         } else {
@@ -307,6 +309,7 @@ int Scene::flatten() {
                 bool finite = true;
                 for (int a = 0; a < 3; a++) finite = finite && std::isfinite(wb.lo[a]) && std::isfinite(wb.hi[a]);
                 prims.push_back(p);
+                prim_anc_id.push_back(f.chain_len > 0 ? f.chain_id : -1);
                 prim_bounds.push_back(wb);
                 prim_bounded.push_back(finite ? 1 : 0);
             }
@@ -585,6 +588,30 @@ int Scene::upload(int dev) {
         std::vector<int32_t> all(prims.size());
         for (size_t i = 0; i < all.size(); i++) all[i] = (int32_t)i;
         if ((rc = upload_vec(*this, all, dscene.all_list))) return rc;
+        // intersection-loop records, once in list order and once in primitive order
+        auto make_leaf = [&](int32_t pi) {
+            const DPrim &p = prims[pi];
+            DLeaf l{};
+            l.type = p.type, l.prim = pi, l.closed = p.closed;
+            l.minimum = p.minimum, l.maximum = p.maximum;
+            l.anc_off = p.chain_off;
+            l.anc_id = prim_anc_id[pi];
+            if (p.type >= PT_TRIANGLE) {
+                l.anc_len = p.chain_len;
+                const DTri &t = tris[p.tri];
+                for (int i = 0; i < 3; i++) l.a[i] = t.p1[i], l.a[3 + i] = t.e1[i], l.a[6 + i] = t.e2[i];
+            } else {
+                l.anc_len = p.chain_len - 1;
+                const DXform &x = xforms[chains[p.chain_off + p.chain_len - 1]];
+                for (int i = 0; i < 12; i++) l.a[i] = x.inv[i];
+            }
+            return l;
+        };
+        std::vector<DLeaf> lv(list.size()), la(prims.size());
+        for (size_t i = 0; i < list.size(); i++) lv[i] = make_leaf(list[i]);
+        for (size_t i = 0; i < prims.size(); i++) la[i] = make_leaf((int32_t)i);
+        if ((rc = upload_vec(*this, lv, dscene.leaves))) return rc;
+        if ((rc = upload_vec(*this, la, dscene.leaves_all))) return rc;
     }
     for (int k = 0; k < 3; k++) dscene.root_min[k] = root_min[k], dscene.root_max[k] = root_max[k];
     dscene.root_ref = root_ref;

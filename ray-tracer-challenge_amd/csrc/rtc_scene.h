@@ -69,6 +69,7 @@ struct Scene {
     std::vector<int32_t> unbounded;
     std::vector<Bounds> prim_bounds;  // world-space, padded; only meaningful for bounded prims
     std::vector<uint8_t> prim_bounded;
+    std::vector<int32_t> prim_anc_id;  // ancestor-chain identity per primitive (-1: top level)
     uint32_t bvh_max_depth = 0, bvh_max_leaf = 0;
     int32_t root_ref = 0;
     double root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};

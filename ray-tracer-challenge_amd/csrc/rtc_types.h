@@ -40,6 +40,23 @@ struct DPrim {
     int32_t chain_id;   // primitives with equal chain_id share the same chain (lane-local ray cache key)
 };
 
+// Intersection-loop record (144 B), one per primitive and per list position: everything a ray/primitive test
+// needs sits in ONE record, so a test costs a single memory round trip (the uniform list is read through the
+// scalar cache, BVH leaves through the vector cache).  `a` holds rows 0..2 of inverse(T_own) for analytic
+// shapes and p1,e1,e2 for triangles (whose own transform is the identity and is skipped, shape.rs:1505-1509).
+// anc_* describe the ANCESTOR (group) transforms only, applied root first before `a`.
+struct DLeaf {
+    int32_t type;
+    int32_t prim;      // flattened (depth-first) primitive index: identity, tie-break order, shading lookup
+    int32_t anc_len;   // number of enclosing groups
+    int32_t anc_off;   // into chains[]
+    int32_t anc_id;    // equal ids <=> same ancestor chain (ray-in-group-space cache key); -1 when anc_len == 0
+    int32_t closed;
+    int32_t pad[2];
+    double minimum, maximum;
+    double a[12];
+};
+
 struct DTri {
     double p1[3], e1[3], e2[3];
     double n1[3], n2[3], n3[3];  // flat triangles: n1 = precomputed face normal
@@ -98,6 +115,8 @@ struct DScene {
     const DBvhNode *bvh;
     const int32_t *prim_list;  // [0, n_unbounded): primitives tested for every ray; then the BVH leaves' runs
     const int32_t *all_list;   // identity 0..n_prims-1 (brute-force mode)
+    const DLeaf *leaves;       // DLeaf records in prim_list order
+    const DLeaf *leaves_all;   // DLeaf records in primitive order (brute-force mode)
     double root_min[3], root_max[3];
     int32_t root_ref;          // child reference of the BVH root (valid when n_bounded > 0)
     int32_t n_prims, n_unbounded, n_bounded, n_bvh_nodes, n_lights, n_materials;
