@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "rtc_scene.h"
 #include "rtc_types.h"
@@ -34,7 +35,7 @@ namespace rtc {
 #define RTC_MAX_DEPTH_STACK 8
 #define RTC_MAX_RAYS_PER_PIXEL 65536
 #ifndef RTC_MIN_WAVES
-#define RTC_MIN_WAVES 2  // waves per SIMD the register allocator must leave room for
+#define RTC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for
 #endif
 
 struct V3 {
@@ -126,17 +127,15 @@ enum Mode { MODE_CLOSEST = 0, MODE_SHADOW = 1, MODE_CONTAINER = 2 };
 // Records whose t is NaN fail every comparison below and are dropped (DESIGN.md "NaN records").
 struct Trace {
     int mode;
-    // MODE_CLOSEST / MODE_SHADOW
-    double best_t;
-    int best_prim;
-    double best_u, best_v;
-    // MODE_CONTAINER
-    double c_thit;
-    int c_hit_prim;
-    double c_best_t;   // latest crossing among OTHER open primitives
-    int c_best_prim;   // -1: none
-    int c_hit_open;    // the hit primitive has an odd number of records before the hit
-    double c_hit_last;
+    // MODE_CLOSEST / MODE_SHADOW: smallest qualifying t so far (initially +inf / the light distance) and its
+    // primitive (-1: none).  MODE_CONTAINER: t and primitive of the hit (fixed during the pass).
+    double lim;
+    int prim;
+    // MODE_CLOSEST: u, v of the best record.  MODE_CONTAINER: latest crossing among OTHER open primitives /
+    // last crossing of the hit primitive.  (The modes are exclusive, so the registers are shared.)
+    double a, b;
+    int c_best_prim;  // MODE_CONTAINER: open primitive with the latest crossing, -1: none
+    int c_hit_open;   // MODE_CONTAINER: the hit primitive has an odd number of records before the hit
     // per-primitive scratch of the container pass
     int n;
     double last;
@@ -144,36 +143,36 @@ struct Trace {
 
 DEV void visit(Trace &T, int pi, double t) {
     if (T.mode == MODE_CONTAINER) {
-        if (t < T.c_thit) {
+        if (t < T.lim) {
             if (T.n == 0 || t >= T.last) T.last = t;
             T.n++;
         }
-    } else if (t > 0. && (t < T.best_t || (t == T.best_t && pi < T.best_prim))) {
-        T.best_t = t;
-        T.best_prim = pi;
+    } else if (t > 0. && (t < T.lim || (t == T.lim && pi < T.prim))) {
+        T.lim = t;
+        T.prim = pi;
     }
 }
 DEV void visit_uv(Trace &T, int pi, double t, double u, double v) {
     if (T.mode == MODE_CONTAINER) {
-        if (t < T.c_thit) {
+        if (t < T.lim) {
             if (T.n == 0 || t >= T.last) T.last = t;
             T.n++;
         }
-    } else if (t > 0. && (t < T.best_t || (t == T.best_t && pi < T.best_prim))) {
-        T.best_t = t;
-        T.best_prim = pi;
-        T.best_u = u;
-        T.best_v = v;
+    } else if (t > 0. && (t < T.lim || (t == T.lim && pi < T.prim))) {
+        T.lim = t;
+        T.prim = pi;
+        T.a = u;
+        T.b = v;
     }
 }
 DEV void end_prim(Trace &T, int pi) {
     if (T.mode == MODE_CONTAINER) {
         if (T.n & 1) {
-            if (pi == T.c_hit_prim) {
+            if (pi == T.prim) {
                 T.c_hit_open = 1;
-                T.c_hit_last = T.last;
-            } else if (T.c_best_prim < 0 || T.last > T.c_best_t || (T.last == T.c_best_t && pi > T.c_best_prim)) {
-                T.c_best_t = T.last;
+                T.b = T.last;
+            } else if (T.c_best_prim < 0 || T.last > T.a || (T.last == T.a && pi > T.c_best_prim)) {
+                T.a = T.last;
                 T.c_best_prim = pi;
             }
         }
@@ -518,6 +517,93 @@ DEV Ray through_ancestors(const DScene &s, int off, int len, Ray r) {
     return r;
 }
 
+// Values that are only touched between intersection passes (the shading context of the current hit and the
+// pixel's accumulated colour) are parked in LDS, [slot][lane] layout, instead of occupying VGPRs during the
+// register-hungry pass: that is what lets RTC_MIN_WAVES waves share a SIMD.  PARK selects how much is parked.
+#define RTC_LDS_STACK 16  // BVH stack entries kept in LDS; deeper entries spill to a per-lane scratch array
+enum ParkSlot {
+    PK_POINT = 0,   // h_point  (3)
+    PK_NORMAL = 3,  // h_normal (3)
+    PK_EYE = 6,     // h_eye    (3)
+    PK_COLOR = 9,   // accumulated pixel colour (3)
+    PK_SURFACE = 12,  // sum of Material::lighting over the lights evaluated so far (3)
+    PK_W = 15,
+    PK_N1 = 16,
+    PK_N2 = 17,
+    PK_COUNT = 18
+};
+DEV void park3(double *base, int slot, V3 v) {
+    base[(slot + 0) * RTC_WAVE] = v.x;
+    base[(slot + 1) * RTC_WAVE] = v.y;
+    base[(slot + 2) * RTC_WAVE] = v.z;
+}
+DEV V3 unpark3(const double *base, int slot) {
+    return mk(base[(slot + 0) * RTC_WAVE], base[(slot + 1) * RTC_WAVE], base[(slot + 2) * RTC_WAVE]);
+}
+
+// Shape::normal_at (shape.rs:43-47): world_to_object down the chain (shape.rs:82-90), local normal,
+// normal_to_world back up with a normalisation per level (shape.rs:94-103).
+template <bool GROUPS>
+DEV V3 normal_at(const DScene &s, const DPrim &p, V3 world_point, double u, double v) {
+    V3 n;
+    if (p.type >= PT_TRIANGLE) {
+        const DTri &tr = s.tris[p.tri];
+        if (p.type == PT_TRIANGLE)
+            n = ld3(tr.n1);  // shape.rs:1516-1518
+        else                 // shape.rs:1749-1754
+            n = ld3(tr.n2) * u + ld3(tr.n3) * v + ld3(tr.n1) * (1. - u - v);
+        // the triangle's own transformation() is the identity (shape.rs:1550-1552): only that level's
+        // normalisation remains
+        n = normalize(n);
+    } else {
+        const double *own = s.xforms[GROUPS ? s.chains[p.chain_off + p.chain_len - 1] : p.own_xform].inv;
+        V3 lp = world_point;
+        if (GROUPS)
+            for (int k = 0; k < p.chain_len - 1; k++) lp = xf_point(s.xforms[s.chains[p.chain_off + k]].inv, lp);
+        switch (p.type) {
+        case PT_PLANE: n = mk(0., 1., 0.); break;  // shape.rs:550-553 (the local point is not read)
+        case PT_SPHERE:                            // shape.rs:273-279
+            lp = xf_point(own, lp);
+            n = lp - mk(0., 0., 0.);
+            break;
+        case PT_CUBE: {  // shape.rs:743-757
+            lp = xf_point(own, lp);
+            const double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
+            const double mc = max3_total(ax, ay, az);
+            if (mc == ax)
+                n = mk(lp.x, 0., 0.);
+            else if (mc == ay)
+                n = mk(0., lp.y, 0.);
+            else
+                n = mk(0., 0., lp.z);
+            break;
+        }
+        default: {  // PT_CYLINDER shape.rs:983-998, PT_CONE shape.rs:1302-1314 (Q8: dist < 1)
+            lp = xf_point(own, lp);
+            const double dist = lp.x * lp.x + lp.z * lp.z;
+            if (dist < 1. && lp.y >= p.maximum - RTC_EPS)
+                n = mk(0., 1., 0.);
+            else if (dist < 1. && lp.y <= p.minimum + RTC_EPS)
+                n = mk(0., -1., 0.);
+            else if (p.type == PT_CYLINDER)
+                n = mk(lp.x, 0., lp.z);
+            else {
+                double yy = sqrt(lp.x * lp.x + lp.z * lp.z);
+                yy = (lp.y > 0.) ? -yy : yy;
+                n = mk(lp.x, yy, lp.z);
+            }
+            break;
+        }
+        }
+        n = normalize(xf_normal(own, n));
+    }
+    if (GROUPS) {
+        const int first_parent = (p.type >= PT_TRIANGLE) ? p.chain_len - 1 : p.chain_len - 2;
+        for (int k = first_parent; k >= 0; k--) n = normalize(xf_normal(s.xforms[s.chains[p.chain_off + k]].inv, n));
+    }
+    return n;
+}
+
 // The megakernel.  Per lane it is a small state machine around ONE intersection pass:
 //   MODE_CLOSEST   World::color_at's closest hit for a primary / reflect / refract ray
 //   MODE_CONTAINER second pass over the same ray for n1/n2 (only for transparent hits)
@@ -528,13 +614,18 @@ DEV Ray through_ancestors(const DScene &s, int off, int len, Ray r) {
 //      switch is a scalar branch;
 //   2. ordered traversal of the binary BVH with the per-lane stack in LDS; leaf records come through the
 //      vector cache, one 144-byte record per test.
-template <bool STATS>
+// Template flags remove state a scene does not need: GROUPS (any primitive has an ancestor group: ray cache
+// in group space, chain walks), PATTERNS (any material has a pattern).
+template <bool STATS, bool GROUPS, bool PATTERNS>
 __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DRenderParams prm,
                                                                      double *__restrict__ out,
                                                                      unsigned long long *__restrict__ stats) {
-    __shared__ int bvh_stack[RTC_BVH_STACK * RTC_WAVE];
+    __shared__ int bvh_stack[RTC_LDS_STACK * RTC_WAVE];
+    __shared__ double parked[PK_COUNT * RTC_WAVE];
     const unsigned lane = threadIdx.x;
     int *const stack = &bvh_stack[lane];  // [entry][lane]: conflict free
+    double *pk = &parked[lane];
+    int deep_stack[RTC_BVH_STACK - RTC_LDS_STACK];  // scratch memory: entries beyond the LDS part (rare)
     const unsigned tile = blockIdx.x;
     const unsigned tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
     const unsigned x = tx * 8u + (lane & 7u);
@@ -551,8 +642,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         for (int i = 0; i < ST_COUNT; i++) cnt.c[i] = 0;
 
     // ---- path state ----
-    V3 color = mk(0., 0., 0.);
-    double w = 1., mult = 1.;
+    park3(pk, PK_COLOR, mk(0., 0., 0.));
+    pk[PK_W * RTC_WAVE] = 1.;
+    double mult = 1.;  // STATS only: how many times the reference traces this ray (Q3)
     int remaining = (int)prm.depth;
     Pending pend[RTC_MAX_DEPTH_STACK];
     int sp = 0;
@@ -563,17 +655,13 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     ray.o = ray.d = mk(0., 0., 0.);
     Trace T;
     T.mode = MODE_CLOSEST;
-    T.best_t = inf, T.best_prim = -1, T.best_u = T.best_v = 0.;
-    T.c_thit = 0., T.c_hit_prim = -1, T.c_best_t = 0., T.c_best_prim = -1, T.c_hit_open = 0, T.c_hit_last = 0.;
+    T.lim = inf, T.prim = -1, T.a = T.b = 0.;
+    T.c_best_prim = -1, T.c_hit_open = 0;
     T.n = 0, T.last = 0.;
     // ---- shading context (valid from the closest hit until the last shadow ray of that hit) ----
     int h_prim = -1;
-    V3 h_point = mk(0., 0., 0.), h_eye = mk(0., 0., 0.), h_normal = mk(0., 0., 0.);
-    double h_n1 = 1., h_n2 = 1.;
-    V3 surface = mk(0., 0., 0.);
     int li = 0;
-    unsigned su = 0, sv = 0;
-    double total = 0.;
+    unsigned su = 0, sv = 0, unshadowed = 0;
 
     if (alive) {
         // Camera::ray_for_pixel, camera.rs:41-59
@@ -596,7 +684,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         // World::intersect (world.rs:176-186) without materialising the list
         // =====================================================================================
         const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
-        int cache_id = -1;    // ancestor chain the cached ray is expressed in
+        int cache_id = -1;  // ancestor chain the cached ray is expressed in (GROUPS)
         Ray cache_ray = ray;
         {
             // ---- phase 1: lockstep walk over the always-tested list (i, L.* are wave-uniform) ----
@@ -604,7 +692,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             for (int i = 0; i < n_lin; i++) {
                 const DLeaf &L = lin[i];
                 Ray r = ray;
-                if (L.anc_len > 0) {
+                if (GROUPS && L.anc_len > 0) {
                     if (L.anc_id != u_cache) {
                         cache_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
                         u_cache = L.anc_id;
@@ -612,7 +700,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     }
                     r = cache_ray;
                 }
-                if (!(any_hit && T.best_prim >= 0)) {
+                if (!(any_hit && T.prim >= 0)) {
                     CNT(ST_XFORM, L.type < PT_TRIANGLE ? 1 : 0);  // the shape's own Ray::transform
                     CNT(ST_PRIM0 + L.type, 1);
                     isect_leaf(L, r, T);
@@ -620,20 +708,34 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             }
             cache_id = u_cache;
         }
-        if (use_bvh && s.n_bounded > 0 && !(any_hit && T.best_prim >= 0)) {
+        if (use_bvh && s.n_bounded > 0 && !(any_hit && T.prim >= 0)) {
             // ---- phase 2: ordered BVH traversal, leaves tested as they are reached ----
             const double lo = (T.mode == MODE_CONTAINER) ? -inf : 0.;
             const V3 inv_d = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
             const V3 oi = mk(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z);
             int pos = 0, end = 0, sb = 0;
             bool root_pending = true;
+#define RTC_PUSH(v)                                                 \
+    do {                                                            \
+        if (sb < RTC_LDS_STACK)                                     \
+            stack[sb * RTC_WAVE] = (v);                             \
+        else if (sb < RTC_BVH_STACK)                                \
+            deep_stack[sb - RTC_LDS_STACK] = (v);                   \
+        sb++;                                                       \
+    } while (0)
+#define RTC_POP(v)                                                                                   \
+    do {                                                                                             \
+        sb--;                                                                                        \
+        (v) = (sb < RTC_LDS_STACK) ? stack[sb * RTC_WAVE]                                            \
+                                   : deep_stack[(sb < RTC_BVH_STACK ? sb : RTC_BVH_STACK - 1) - RTC_LDS_STACK]; \
+    } while (0)
             for (;;) {
                 if (pos < end) {
                     const DLeaf &L = s.leaves[pos++];
                     // Ray::transform down the ancestor chain, root first (shape.rs:2035).  Primitives of one
                     // group share it: the ray in group space is cached per lane.
                     Ray r = ray;
-                    if (L.anc_len > 0) {
+                    if (GROUPS && L.anc_len > 0) {
                         if (L.anc_id != cache_id) {
                             cache_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
                             cache_id = L.anc_id;
@@ -644,7 +746,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     CNT(ST_XFORM, L.type < PT_TRIANGLE ? 1 : 0);
                     CNT(ST_PRIM0 + L.type, 1);
                     isect_leaf(L, r, T);
-                    if (any_hit && T.best_prim >= 0) break;
+                    if (any_hit && T.prim >= 0) break;
                     continue;
                 }
                 // ---- next leaf ----
@@ -653,36 +755,31 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     root_pending = false;
                     double tn;
                     CNT(ST_BOX, 1);
-                    if (!slab(s.root_min, s.root_max, inv_d, oi, lo, (T.mode == MODE_CONTAINER) ? T.c_thit : T.best_t,
-                              tn))
-                        break;
+                    if (!slab(s.root_min, s.root_max, inv_d, oi, lo, T.lim, tn)) break;
                     ref = s.root_ref;
                 } else if (sb > 0) {
-                    sb--;
-                    ref = stack[sb * RTC_WAVE];
+                    RTC_POP(ref);
                 } else {
                     break;
                 }
                 bool finished = false;
                 while (ref >= 0) {
                     const DBvhNode &n = s.bvh[ref];
-                    const double hi = (T.mode == MODE_CONTAINER) ? T.c_thit : T.best_t;
                     double tl, tr;
                     CNT(ST_BOX, 2);
-                    const bool hl = slab(n.lmin, n.lmax, inv_d, oi, lo, hi, tl);
-                    const bool hr = slab(n.rmin, n.rmax, inv_d, oi, lo, hi, tr);
+                    const bool hl = slab(n.lmin, n.lmax, inv_d, oi, lo, T.lim, tl);
+                    const bool hr = slab(n.rmin, n.rmax, inv_d, oi, lo, T.lim, tr);
                     const int cl = n.left, cr = n.right;
                     if (hl && hr) {
                         const bool left_first = tl <= tr;
-                        if (sb < RTC_BVH_STACK) stack[sb * RTC_WAVE] = left_first ? cr : cl, sb++;
+                        RTC_PUSH(left_first ? cr : cl);
                         ref = left_first ? cl : cr;
                     } else if (hl) {
                         ref = cl;
                     } else if (hr) {
                         ref = cr;
                     } else if (sb > 0) {
-                        sb--;
-                        ref = stack[sb * RTC_WAVE];
+                        RTC_POP(ref);
                     } else {
                         finished = true;
                         break;
@@ -693,7 +790,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 pos = code >> 3;
                 end = pos + (code & 7) + 1;
             }
+#undef RTC_PUSH
+#undef RTC_POP
         }
+        // the parked values are re-read from LDS after a pass, never carried in registers across it
+        asm volatile("" : "+v"(pk));
 
         // =====================================================================================
         // state machine
@@ -701,73 +802,27 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         bool begin_lights = false, finish = false, next_ray = false, need_shadow = false;
         if (T.mode == MODE_CLOSEST) {
             // World::color_at, world.rs:30-38
-            if (T.best_prim < 0 || s.n_lights == 0) {
+            if (T.prim < 0 || s.n_lights == 0) {
                 next_ray = true;
             } else {
-                const DPrim &p = s.prims[T.best_prim];
+                const DPrim &p = s.prims[T.prim];
                 const DMaterial &m = s.materials[p.material];
                 // Intersection::prepare_computations, intersection.rs:123-148
-                h_prim = T.best_prim;
-                h_point = ray.o + ray.d * T.best_t;
-                h_eye = -ray.d;
-                // Shape::normal_at (shape.rs:43-47): world_to_object down the chain (shape.rs:82-90), local
-                // normal, normal_to_world back up with a normalisation per level (shape.rs:94-103).
-                V3 n;
-                if (p.type >= PT_TRIANGLE) {
-                    const DTri &tr = s.tris[p.tri];
-                    if (p.type == PT_TRIANGLE)
-                        n = ld3(tr.n1);  // shape.rs:1516-1518
-                    else                 // shape.rs:1749-1754
-                        n = ld3(tr.n2) * T.best_u + ld3(tr.n3) * T.best_v + ld3(tr.n1) * (1. - T.best_u - T.best_v);
-                    // the triangle's own transformation() is the identity (shape.rs:1550-1552): only that
-                    // level's normalisation remains
-                    n = normalize(n);
-                } else {
-                    V3 lp = h_point;
-                    for (int k = 0; k < p.chain_len; k++) lp = xf_point(s.xforms[s.chains[p.chain_off + k]].inv, lp);
-                    switch (p.type) {
-                    case PT_SPHERE: n = lp - mk(0., 0., 0.); break;  // shape.rs:273-279
-                    case PT_PLANE: n = mk(0., 1., 0.); break;         // shape.rs:550-553
-                    case PT_CUBE: {                                   // shape.rs:743-757
-                        const double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
-                        const double mc = max3_total(ax, ay, az);
-                        if (mc == ax)
-                            n = mk(lp.x, 0., 0.);
-                        else if (mc == ay)
-                            n = mk(0., lp.y, 0.);
-                        else
-                            n = mk(0., 0., lp.z);
-                        break;
-                    }
-                    default: {  // PT_CYLINDER shape.rs:983-998, PT_CONE shape.rs:1302-1314 (Q8: dist < 1)
-                        const double dist = lp.x * lp.x + lp.z * lp.z;
-                        if (dist < 1. && lp.y >= p.maximum - RTC_EPS)
-                            n = mk(0., 1., 0.);
-                        else if (dist < 1. && lp.y <= p.minimum + RTC_EPS)
-                            n = mk(0., -1., 0.);
-                        else if (p.type == PT_CYLINDER)
-                            n = mk(lp.x, 0., lp.z);
-                        else {
-                            double yy = sqrt(lp.x * lp.x + lp.z * lp.z);
-                            yy = (lp.y > 0.) ? -yy : yy;
-                            n = mk(lp.x, yy, lp.z);
-                        }
-                        break;
-                    }
-                    }
-                    n = normalize(xf_normal(s.xforms[s.chains[p.chain_off + p.chain_len - 1]].inv, n));
-                }
-                const int first_parent = (p.type >= PT_TRIANGLE) ? p.chain_len - 1 : p.chain_len - 2;
-                for (int k = first_parent; k >= 0; k--)
-                    n = normalize(xf_normal(s.xforms[s.chains[p.chain_off + k]].inv, n));
+                h_prim = T.prim;
+                const V3 h_point = ray.o + ray.d * T.lim;
+                const V3 h_eye = -ray.d;
+                V3 n = normal_at<GROUPS>(s, p, h_point, T.a, T.b);
                 if (dot(n, h_eye) < 0.) n = -n;  // intersection.rs:134-139
-                h_normal = n;
-                h_n1 = h_n2 = 1.;
+                park3(pk, PK_POINT, h_point);
+                park3(pk, PK_EYE, h_eye);
+                park3(pk, PK_NORMAL, n);
+                pk[PK_N1 * RTC_WAVE] = 1.;
+                pk[PK_N2 * RTC_WAVE] = 1.;
                 CNT(ST_SHADED, 1);
                 if (remaining > 0 && m.transparency != 0.) {
-                    // containers loop (intersection.rs:150-179) in streaming form: second pass over the same ray
-                    T.c_thit = T.best_t, T.c_hit_prim = T.best_prim;
-                    T.c_best_t = 0., T.c_best_prim = -1, T.c_hit_open = 0, T.c_hit_last = 0.;
+                    // containers loop (intersection.rs:150-179) in streaming form: second pass over the same
+                    // ray with T.lim / T.prim (the hit) held fixed
+                    T.a = 0., T.b = 0., T.c_best_prim = -1, T.c_hit_open = 0;
                     T.mode = MODE_CONTAINER;
                     CNT(ST_CONTAINER, 1);
                     continue;
@@ -778,49 +833,54 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             const double ri_hit = s.materials[s.prims[h_prim].material].refractive_index;
             const double ri_other =
                 (T.c_best_prim >= 0) ? s.materials[s.prims[T.c_best_prim].material].refractive_index : 1.;
+            double n1, n2;
             if (T.c_hit_open) {
                 // the hit primitive leaves: n1 = last of (others + hit), n2 = last of the others
-                const bool hit_is_last = T.c_best_prim < 0 || T.c_hit_last > T.c_best_t ||
-                                         (T.c_hit_last == T.c_best_t && h_prim > T.c_best_prim);
-                h_n1 = hit_is_last ? ri_hit : ri_other;
-                h_n2 = ri_other;
+                const bool hit_is_last =
+                    T.c_best_prim < 0 || T.b > T.a || (T.b == T.a && h_prim > T.c_best_prim);
+                n1 = hit_is_last ? ri_hit : ri_other;
+                n2 = ri_other;
             } else {
                 // the hit primitive enters and becomes the last container
-                h_n1 = ri_other;
-                h_n2 = ri_hit;
+                n1 = ri_other;
+                n2 = ri_hit;
             }
+            pk[PK_N1 * RTC_WAVE] = n1;
+            pk[PK_N2 * RTC_WAVE] = n2;
             begin_lights = true;
         } else {
             // World::is_shadowed (world.rs:78-91): only the NEAREST positive hit is consulted (Q5); when every
             // material casts shadows that equals "some hit has 0 < t < distance" (any-hit early exit).
             const bool shadowed =
-                T.best_prim >= 0 && (s.all_cast_shadow || s.materials[s.prims[T.best_prim].material].casts_shadow != 0);
+                T.prim >= 0 && (s.all_cast_shadow || s.materials[s.prims[T.prim].material].casts_shadow != 0);
             const DLight &lt = s.lights[li];
             bool have = true;
             double inten;
-            if (lt.is_area) {  // light.rs:112-125
-                if (!shadowed) total += 1.;
+            if (lt.is_area) {  // light.rs:112-125: total += 1.0 per unshadowed sample, then total / samples
+                if (!shadowed) unshadowed++;
                 su++;
                 if (su >= lt.usteps) su = 0, sv++;
                 if (sv < lt.vsteps) {
                     have = false;
                     need_shadow = true;
                 }
-                inten = total / (double)lt.samples;
+                inten = (double)unshadowed / (double)lt.samples;
             } else {  // light.rs:50-56
                 inten = shadowed ? 0. : 1.;
             }
             if (have) {
                 const DPrim &p = s.prims[h_prim];
                 const DMaterial &m = s.materials[p.material];
-                const V3 over = h_point + h_normal * RTC_EPS;
-                const V3 col = (m.pattern >= 0) ? pattern_at_shape(s, m.pattern, p, over) : ld3(m.color);
-                const V3 c = lighting(m, col, ld3(lt.position), ld3(lt.intensity), over, h_eye, h_normal, inten);
+                const V3 over = ray.o;  // the shadow ray starts at over_point (world.rs:50, 79)
+                V3 col = ld3(m.color);
+                if (PATTERNS && m.pattern >= 0) col = pattern_at_shape(s, m.pattern, p, over);
+                const V3 c = lighting(m, col, ld3(lt.position), ld3(lt.intensity), over, unpark3(pk, PK_EYE),
+                                      unpark3(pk, PK_NORMAL), inten);
                 CNT(ST_LIGHT, 1);
-                surface = (li == 0) ? c : surface + c;  // world.rs:70 left fold
+                park3(pk, PK_SURFACE, (li == 0) ? c : unpark3(pk, PK_SURFACE) + c);  // world.rs:70 left fold
                 li++;
                 su = sv = 0;
-                total = 0.;
+                unshadowed = 0;
                 if (li < s.n_lights)
                     need_shadow = true;
                 else
@@ -828,61 +888,67 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             }
         }
         if (begin_lights) {
-            li = 0, su = sv = 0, total = 0.;
+            li = 0, su = sv = 0, unshadowed = 0;
             need_shadow = true;
         }
         if (finish) {
             // World::shade_hit (world.rs:42-76).  The reference evaluates reflected_color/refracted_color inside
             // the per-light loop (Q3), i.e. adds them n_lights times: that factor goes into the child's weight.
             const DMaterial &m = s.materials[s.prims[h_prim].material];
-            color = color + surface * w;
+            const double w = pk[PK_W * RTC_WAVE];
+            park3(pk, PK_COLOR, unpark3(pk, PK_COLOR) + unpark3(pk, PK_SURFACE) * w);
             next_ray = true;
             if (remaining > 0) {
                 const bool refl = m.reflectivity != 0.;
                 const bool refr = m.transparency != 0.;
-                double kr = 1., kt = 1.;
-                if (m.reflectivity > 0. && m.transparency > 0.) {
-                    const double r = schlick(h_n1, h_n2, h_eye, h_normal);
-                    CNT(ST_SCHLICK, 1);
-                    kr = r;
-                    kt = 1. - r;
-                }
-                if (refr) {
-                    // refracted_color, world.rs:108-147
-                    const double n_ratio = h_n1 / h_n2;
-                    const double cos_i = dot(h_eye, h_normal);
-                    const double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
-                    CNT(ST_REFRACT, 1);
-                    if (!(sin2_t > 1.)) {
-                        const double cos_t = sqrt(1. - sin2_t);
-                        Pending q;
-                        q.o = h_point - h_normal * RTC_EPS;  // under_point
-                        q.d = h_normal * (n_ratio * cos_i - cos_t) - h_eye * n_ratio;
-                        q.w = w * (nl * (m.transparency * kt));
-                        q.mult = mult * nl;
-                        q.remaining = remaining;  // Q2: not decremented (world.rs:142)
-                        if (sp < RTC_MAX_DEPTH_STACK) {
-                            pend[sp] = q;
-                            sp++;
-                        } else {
-                            CNT(ST_OVERFLOW, 1);
+                if (refl || refr) {
+                    const V3 h_point = unpark3(pk, PK_POINT), h_normal = unpark3(pk, PK_NORMAL);
+                    const V3 h_eye = unpark3(pk, PK_EYE);
+                    const double h_n1 = pk[PK_N1 * RTC_WAVE], h_n2 = pk[PK_N2 * RTC_WAVE];
+                    double kr = 1., kt = 1.;
+                    if (m.reflectivity > 0. && m.transparency > 0.) {
+                        const double r = schlick(h_n1, h_n2, h_eye, h_normal);
+                        CNT(ST_SCHLICK, 1);
+                        kr = r;
+                        kt = 1. - r;
+                    }
+                    if (refr) {
+                        // refracted_color, world.rs:108-147
+                        const double n_ratio = h_n1 / h_n2;
+                        const double cos_i = dot(h_eye, h_normal);
+                        const double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+                        CNT(ST_REFRACT, 1);
+                        if (!(sin2_t > 1.)) {
+                            const double cos_t = sqrt(1. - sin2_t);
+                            Pending q;
+                            q.o = h_point - h_normal * RTC_EPS;  // under_point
+                            q.d = h_normal * (n_ratio * cos_i - cos_t) - h_eye * n_ratio;
+                            q.w = w * (nl * (m.transparency * kt));
+                            q.mult = STATS ? mult * nl : 0.;
+                            q.remaining = remaining;  // Q2: not decremented (world.rs:142)
+                            if (sp < RTC_MAX_DEPTH_STACK) {
+                                pend[sp] = q;
+                                sp++;
+                            } else {
+                                CNT(ST_OVERFLOW, 1);
+                            }
                         }
                     }
-                }
-                if (refl) {
-                    // reflected_color, world.rs:93-106
-                    const V3 d_in = -h_eye;
-                    ray.o = h_point + h_normal * RTC_EPS;  // over_point
-                    ray.d = reflect(d_in, h_normal);
-                    w = w * (nl * (m.reflectivity * kr));
-                    mult = mult * nl;
-                    remaining -= 1;
-                    next_ray = false;
-                    T.mode = MODE_CLOSEST;
-                    T.best_t = inf, T.best_prim = -1;
-                    CNT(ST_SECONDARY, 1);
-                    CNT(ST_SECONDARY_REF, mult);
-                    rays++;
+                    if (refl) {
+                        // reflected_color, world.rs:93-106
+                        const V3 d_in = -h_eye;
+                        ray.o = h_point + h_normal * RTC_EPS;  // over_point
+                        ray.d = reflect(d_in, h_normal);
+                        pk[PK_W * RTC_WAVE] = w * (nl * (m.reflectivity * kr));
+                        if (STATS) mult = mult * nl;
+                        remaining -= 1;
+                        next_ray = false;
+                        T.mode = MODE_CLOSEST;
+                        T.lim = inf, T.prim = -1;
+                        CNT(ST_SECONDARY, 1);
+                        CNT(ST_SECONDARY_REF, mult);
+                        rays++;
+                    }
                 }
             }
         }
@@ -892,9 +958,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             } else {
                 sp--;
                 const Pending q = pend[sp];
-                ray.o = q.o, ray.d = q.d, w = q.w, mult = q.mult, remaining = q.remaining;
+                ray.o = q.o, ray.d = q.d, remaining = q.remaining;
+                pk[PK_W * RTC_WAVE] = q.w;
+                if (STATS) mult = q.mult;
                 T.mode = MODE_CLOSEST;
-                T.best_t = inf, T.best_prim = -1;
+                T.lim = inf, T.prim = -1;
                 CNT(ST_SECONDARY, 1);
                 CNT(ST_SECONDARY_REF, mult);
                 rays++;
@@ -905,23 +973,24 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             V3 lp = ld3(lt.position);
             if (lt.is_area)  // AreaLight::point_on_light, light.rs:106-108
                 lp = ld3(lt.corner) + ld3(lt.uvec) * ((double)su + 0.5) + ld3(lt.vvec) * ((double)sv + 0.5);
-            const V3 over = h_point + h_normal * RTC_EPS;
+            const V3 over = unpark3(pk, PK_POINT) + unpark3(pk, PK_NORMAL) * RTC_EPS;
             const V3 dv = lp - over;  // world.rs:79-83
             ray.o = over;
             ray.d = normalize(dv);
-            T.best_t = magnitude(dv);
-            T.best_prim = -1;
+            T.lim = magnitude(dv);
+            T.prim = -1;
             T.mode = MODE_SHADOW;
             CNT(ST_SHADOW, 1);
         }
         if (rays > RTC_MAX_RAYS_PER_PIXEL) {
             CNT(ST_OVERFLOW, 1);
-            color = mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.);
+            park3(pk, PK_COLOR, mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.));
             alive = false;
         }
     }
 
     if (in_image) {
+        const V3 color = unpark3(pk, PK_COLOR);
         double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
         px[0] = color.x, px[1] = color.y, px[2] = color.z;
     }
@@ -939,12 +1008,17 @@ int launch_render(const DScene &scene, const DRenderParams &params, double *d_rg
     const unsigned tiles = params.tiles_x * params.tiles_y;
     if (tiles == 0) return RTC_OK;
     hipStream_t st = (hipStream_t)stream;
+    static const unsigned lds_pad = getenv("RTC_LDS_PAD") ? (unsigned)atoi(getenv("RTC_LDS_PAD")) : 0u;  // occupancy experiments
+    unsigned long long *ds = (unsigned long long *)d_stats;
+    const dim3 grid(tiles), block(RTC_WAVE);
     if (collect_stats)
-        hipLaunchKernelGGL(k_render<true>, dim3(tiles), dim3(RTC_WAVE), 0, st, scene, params, d_rgb,
-                           (unsigned long long *)d_stats);
+        hipLaunchKernelGGL((k_render<true, true, true>), grid, block, lds_pad, st, scene, params, d_rgb, ds);
+    else if (scene.any_pattern)
+        hipLaunchKernelGGL((k_render<false, true, true>), grid, block, lds_pad, st, scene, params, d_rgb, ds);
+    else if (scene.any_group)
+        hipLaunchKernelGGL((k_render<false, true, false>), grid, block, lds_pad, st, scene, params, d_rgb, ds);
     else
-        hipLaunchKernelGGL(k_render<false>, dim3(tiles), dim3(RTC_WAVE), 0, st, scene, params, d_rgb,
-                           (unsigned long long *)d_stats);
+        hipLaunchKernelGGL((k_render<false, false, false>), grid, block, lds_pad, st, scene, params, d_rgb, ds);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("kernel launch failed: %s", hipGetErrorString(e));

@@ -623,6 +623,9 @@ int Scene::upload(int dev) {
     dscene.n_materials = (int32_t)dmaterials.size();
     dscene.all_cast_shadow = 1;
     dscene.any_pattern = 0;
+    dscene.any_group = 0;
+    for (int32_t id : prim_anc_id)
+        if (id >= 0) dscene.any_group = 1;
     for (const DMaterial &m : dmaterials) {
         if (!m.casts_shadow) dscene.all_cast_shadow = 0;
         if (m.pattern >= 0) dscene.any_pattern = 1;

@@ -122,7 +122,7 @@ struct DScene {
     int32_t n_prims, n_unbounded, n_bounded, n_bvh_nodes, n_lights, n_materials;
     int32_t all_cast_shadow;  // 1 if every material has casts_shadow: shadow rays may stop at any hit
     int32_t any_pattern;
-    int32_t pad;
+    int32_t any_group;        // 1 if some primitive sits inside a group (ancestor transforms exist)
 };
 
 struct DRenderParams {
