@@ -532,12 +532,13 @@ enum ParkSlot {
     PK_N2 = 17,
     PK_COUNT = 18
 };
-DEV void park3(double *base, int slot, V3 v) {
+typedef __attribute__((address_space(3))) double lds_f64;  // an LDS pointer the compiler can not mistake for flat
+DEV void park3(lds_f64 *base, int slot, V3 v) {
     base[(slot + 0) * RTC_WAVE] = v.x;
     base[(slot + 1) * RTC_WAVE] = v.y;
     base[(slot + 2) * RTC_WAVE] = v.z;
 }
-DEV V3 unpark3(const double *base, int slot) {
+DEV V3 unpark3(const lds_f64 *base, int slot) {
     return mk(base[(slot + 0) * RTC_WAVE], base[(slot + 1) * RTC_WAVE], base[(slot + 2) * RTC_WAVE]);
 }
 
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     __shared__ double parked[PK_COUNT * RTC_WAVE];
     const unsigned lane = threadIdx.x;
     int *const stack = &bvh_stack[lane];  // [entry][lane]: conflict free
-    double *pk = &parked[lane];
+    lds_f64 *const pk = (lds_f64 *)parked + lane;
     int deep_stack[RTC_BVH_STACK - RTC_LDS_STACK];  // scratch memory: entries beyond the LDS part (rare)
     const unsigned tile = blockIdx.x;
     const unsigned tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
@@ -793,8 +794,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
 #undef RTC_PUSH
 #undef RTC_POP
         }
-        // the parked values are re-read from LDS after a pass, never carried in registers across it
-        asm volatile("" : "+v"(pk));
+        // (the parked values are re-read from LDS after a pass; the compiler does not carry them across it --
+        // checked in the ISA: no launder is needed, and an asm barrier here would cost the scalar loads above)
 
         // =====================================================================================
         // state machine
