@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (scene file, width, height)
     "teapot_4k": ("teapot", 3840, 2160),
+    "stress_4k": ("stress", 3840, 2160),  # BASELINE.json configs[4]: 100k glass/mirror spheres + teapot
     "cover_4k": ("cover", 3840, 2160),
     "cover_1080p": ("cover", 1920, 1080),
     "reflective_world_1080p": ("reflective_world", 1920, 1080),
@@ -46,6 +47,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-stride", type=int, default=0, help="0 = choose for ~10-20 s of CPU work")
     ap.add_argument("--use-bvh", type=int, default=0, help="0 auto, 1 force BVH, 2 force brute force (A/B only)")
+    ap.add_argument("--schedule", type=int, default=0, help="0 auto, 1 workgroup per tile, 2 persistent (A/B only)")
+    ap.add_argument("--extra-stress", action="store_true", help="include the (slow) stress scene in --extra")
     ap.add_argument("--extra", action="store_true", help="also time the other workloads (untimed region, N=1)")
     args = ap.parse_args()
 
@@ -71,6 +74,8 @@ def main():
 
     def load(workload):
         name, w, h = WORKLOADS[workload]
+        if name == "stress":
+            return rtc.stress_scene.build(100_000, w, h)
         sc = rtc.parse_scene_file(os.path.join(ROOT, "scenes", name + ".yaml"), w, h)
         return rtc.World(sc.objects, sc.lights), sc.camera
 
@@ -79,6 +84,8 @@ def main():
     hsize, vsize = cam.hsize, cam.vsize
     tile = dict(tile_rows=TILE_ROWS, tile_index=rank, tile_count=world_size) if distributed else {}
     ropts = dict(tile)
+    if args.schedule:
+        ropts["schedule"] = args.schedule
     if args.use_bvh:
         ropts["use_bvh"] = args.use_bvh
     local_rows = scene.local_rows(**tile) if distributed else vsize
@@ -173,7 +180,7 @@ def main():
         except Exception:
             traffic = None
     out = {
-        "metric": "Mrays/s (primary+shadow+secondary), teapot.yaml @3840x2160",
+        "metric": "Mrays/s (primary+shadow+secondary), %s @%dx%d" % (WORKLOADS[args.workload][0], hsize, vsize),
         "value": value,
         "unit": "Mrays/s",
         "n_gpus": n_gpus,
@@ -185,7 +192,8 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "reference sample scene (scenes/%s.yaml, camera resized)" % WORKLOADS[args.workload][0],
+        "data": ("synthetic stress scene (stress_scene.py, seed 0x5EED1234)" if args.workload == "stress_4k" else
+                 "reference sample scene (scenes/%s.yaml, camera resized)" % WORKLOADS[args.workload][0]),
         "config": {
             "workload": "%s: scenes/%s.yaml at %dx%d, depth 5, %d active pixels" % (
                 args.workload, WORKLOADS[args.workload][0], hsize, vsize, (hsize - 1) * (vsize - 1)),
@@ -220,12 +228,14 @@ def main():
     if args.extra and not distributed:
         extra = {}
         for wl in WORKLOADS:
-            if wl == args.workload:
+            if wl == args.workload or (wl == "stress_4k" and not args.extra_stress):
                 continue
             w2, c2 = load(wl)
             s2 = c2.compile(w2, device=local_rank)
             b2 = torch.zeros((c2.vsize, c2.hsize, 3), dtype=torch.float64, device=dev)
             kw2 = {"use_bvh": args.use_bvh} if args.use_bvh else {}
+            if args.schedule:
+                kw2["schedule"] = args.schedule
             s2.render_device(b2.data_ptr(), stream.cuda_stream, collect_stats=True, **kw2)
             st2 = s2.stats()
             for _ in range(2):

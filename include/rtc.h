@@ -75,7 +75,8 @@ typedef struct rtc_render_opts {
     uint32_t tile_count; /* number of ranks (1 = everything) */
     uint32_t use_bvh;    /* 0 = auto, 1 = force BVH traversal, 2 = force brute-force linear scan */
     uint32_t collect_stats; /* 1 = run the counting variant of the kernel and fill the ray/test counters */
-    uint32_t reserved[2];
+    uint32_t schedule;   /* 0 = auto, 1 = one workgroup per 8x8 tile, 2 = persistent grid with lane refill */
+    uint32_t reserved[1];
 } rtc_render_opts;
 
 /* Work counters (filled when collect_stats != 0) and timing of the last launch. */

@@ -3,7 +3,7 @@ anna-hope/ray-tracer-challenge (Camera::render -> World::color_at -> ...), behin
 interface names.  The compute lives in librtc_amd.so (HIP kernels for gfx950 + host flattener/BVH, C ABI in
 include/rtc.h); this package is the thin host-side mirror.  There is no CPU render path here.
 """
-from . import _native, parallel
+from . import _native, parallel, stress_scene
 from ._native import NonInvertibleMatrix, RtcError
 from .api import (AreaLight, BlendedPattern, Camera, Canvas, CheckerPattern, CompiledScene, Cone, Cube, Cylinder,
                   GradientPattern, Group, Material, Matrix, Pattern, Plane, PointLight, RadialGradientPattern,

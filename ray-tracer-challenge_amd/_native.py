@@ -51,7 +51,8 @@ class RenderOpts(C.Structure):
         ("tile_count", C.c_uint32),
         ("use_bvh", C.c_uint32),
         ("collect_stats", C.c_uint32),
-        ("reserved", C.c_uint32 * 2),
+        ("schedule", C.c_uint32),
+        ("reserved", C.c_uint32 * 1),
     ]
 
 

@@ -388,11 +388,12 @@ class CompiledScene:
             raise TypeError(f"unsupported object {type(obj)}")
 
     # ---- rendering ----
-    def _opts(self, depth=5, tile_rows=0, tile_index=0, tile_count=1, use_bvh=0, collect_stats=False):
+    def _opts(self, depth=5, tile_rows=0, tile_index=0, tile_count=1, use_bvh=0, collect_stats=False, schedule=0):
         o = N.RenderOpts()
         self.L.rtc_render_opts_default(C.byref(o))
         o.depth, o.tile_rows, o.tile_index, o.tile_count = depth, tile_rows, tile_index, tile_count
         o.use_bvh, o.collect_stats = use_bvh, 1 if collect_stats else 0
+        o.schedule = schedule
         return o
 
     def render(self, **kw):

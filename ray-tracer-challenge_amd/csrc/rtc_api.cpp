@@ -267,6 +267,8 @@ static int resolve_params(Scene &s, const rtc_render_opts *opts_in, DRenderParam
     // auto: the BVH pays as soon as a few bounded primitives exist
     const size_t bounded = s.prims.size() - s.unbounded.size();
     p.use_bvh = (o.use_bvh == 1) ? 1u : (o.use_bvh == 2) ? 0u : (bounded > 4 ? 1u : 0u);
+    // auto: deep ray trees come from transparent surfaces (refraction keeps the bounce budget, world.rs:142)
+    p.persistent = (o.schedule == 2) ? 1u : (o.schedule == 1) ? 0u : (s.n_transparent_prims > 64 ? 1u : 0u);
     p.tiles_x = (s.hsize + 7u) / 8u;
     p.tiles_y = (p.local_rows + 7u) / 8u;
     // the explicit per-lane stack holds one pending refraction per distinct `remaining` value
@@ -338,7 +340,7 @@ int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_r
         std::memset(&s.last_stats, 0, sizeof s.last_stats);
         s.last_stats.pixels = (uint64_t)(s.hsize - 1) * 0;  // filled by rtc_scene_last_stats
     }
-    return launch_render(s.dscene, p, d_rgb, s.d_stats, o.collect_stats != 0, hip_stream);
+    return launch_render(s.dscene, p, d_rgb, s.d_stats, s.d_work, s.max_waves, o.collect_stats != 0, hip_stream);
 }
 
 int rtc_scene_last_stats(rtc_scene *scene, rtc_stats *stats) {
@@ -395,7 +397,7 @@ int rtc_render(rtc_scene *scene, const rtc_render_opts *opts, double *rgb_out, r
     hipStream_t st = nullptr;
     if (o.collect_stats) (void)hipMemsetAsync(s.d_stats, 0, sizeof(uint64_t) * ST_COUNT, st);
     (void)hipEventRecord((hipEvent_t)s.ev_start, st);
-    rc = launch_render(s.dscene, p, d_rgb, s.d_stats, o.collect_stats != 0, st);
+    rc = launch_render(s.dscene, p, d_rgb, s.d_stats, s.d_work, s.max_waves, o.collect_stats != 0, st);
     (void)hipEventRecord((hipEvent_t)s.ev_stop, st);
     if (rc == RTC_OK) {
         const hipError_t e = hipEventSynchronize((hipEvent_t)s.ev_stop);

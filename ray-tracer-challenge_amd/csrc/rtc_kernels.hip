@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
 #include "rtc_scene.h"
@@ -34,6 +35,10 @@ namespace rtc {
 #define RTC_BVH_STACK 32
 #define RTC_MAX_DEPTH_STACK 8
 #define RTC_MAX_RAYS_PER_PIXEL 65536
+#define RTC_SHARDS 8u  // tile counters of the persistent grid
+#ifndef RTC_REFILL_MIN
+#define RTC_REFILL_MIN 1  // free lanes needed before a wave assigns new pixels
+#endif
 #ifndef RTC_MIN_WAVES
 #define RTC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for
 #endif
@@ -74,11 +79,13 @@ DEV V3 reflect(V3 v, V3 n) {  // tuple.rs:122-124: self - (normal * 2.) * self.d
 DEV bool approx_zero(double a) { return fabs(a - 0.) < RTC_EPS; }  // lib.rs:26-29 equal(a, 0.)
 
 // matrix.rs:328-346 / 348-365 on a 3x4 row-major inverse
-DEV V3 xf_point(const double *m, V3 p) {
+template <class M>
+DEV V3 xf_point(M m, V3 p) {
     return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
               m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
 }
-DEV V3 xf_vector(const double *m, V3 v) {
+template <class M>
+DEV V3 xf_vector(M m, V3 v) {
     return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
               m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
@@ -296,8 +303,9 @@ DEV void isect_cone(const Ray &r, double minimum, double maximum, int closed, Tr
 }
 
 // shape.rs:1479-1502 == 1712-1735; a = p1, e1, e2
-DEV void isect_triangle(const Ray &r, const double *a, Trace &T, int pi) {
-    const V3 p1 = ld3(a), e1 = ld3(a + 3), e2 = ld3(a + 6);
+template <class P>
+DEV void isect_triangle(const Ray &r, P a, Trace &T, int pi) {
+    const V3 p1 = mk(a[0], a[1], a[2]), e1 = mk(a[3], a[4], a[5]), e2 = mk(a[6], a[7], a[8]);
     const V3 dce2 = cross(r.d, e2);
     const double det = dot(e1, dce2);
     if (fabs(det) < RTC_EPS) return;
@@ -315,9 +323,10 @@ DEV void isect_triangle(const Ray &r, const double *a, Trace &T, int pi) {
 // shapes): Shape::intersect = ray.transform(inverse(T_own)) + local_intersect (e.g. shape.rs:254-258).  A plane
 // only ever reads the y components of the object-space ray, so only row 1 of the product is formed (the
 // arithmetic of that row is unchanged).
-DEV void isect_leaf(const DLeaf &L, const Ray &r, Trace &T) {
+template <class Leaf>
+DEV void isect_leaf(const Leaf &L, const Ray &r, Trace &T) {
     const int pi = L.prim;
-    const double *m = L.a;
+    const auto *m = L.a;  // keeps the record's address space (constant for the lockstep list)
     switch (L.type) {
     case PT_PLANE: {  // shape.rs:510-517
         const double oy = m[4] * r.o.x + m[5] * r.o.y + m[6] * r.o.z + m[7];
@@ -520,7 +529,10 @@ DEV Ray through_ancestors(const DScene &s, int off, int len, Ray r) {
 // Values that are only touched between intersection passes (the shading context of the current hit and the
 // pixel's accumulated colour) are parked in LDS, [slot][lane] layout, instead of occupying VGPRs during the
 // register-hungry pass: that is what lets RTC_MIN_WAVES waves share a SIMD.  PARK selects how much is parked.
-#define RTC_LDS_STACK 16  // BVH stack entries kept in LDS; deeper entries spill to a per-lane scratch array
+#ifndef RTC_LDS_STACK
+#define RTC_LDS_STACK 16
+#endif
+//  // BVH stack entries kept in LDS; deeper entries spill to a per-lane scratch array
 enum ParkSlot {
     PK_POINT = 0,   // h_point  (3)
     PK_NORMAL = 3,  // h_normal (3)
@@ -617,36 +629,40 @@ DEV V3 normal_at(const DScene &s, const DPrim &p, V3 world_point, double u, doub
 //      vector cache, one 144-byte record per test.
 // Template flags remove state a scene does not need: GROUPS (any primitive has an ancestor group: ray cache
 // in group space, chain walks), PATTERNS (any material has a pattern).
-template <bool STATS, bool GROUPS, bool PATTERNS>
+template <bool STATS, bool GROUPS, bool PATTERNS, bool PERSISTENT>
 __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DRenderParams prm,
                                                                      double *__restrict__ out,
-                                                                     unsigned long long *__restrict__ stats) {
+                                                                     unsigned long long *__restrict__ stats,
+                                                                     unsigned *__restrict__ work) {
     __shared__ int bvh_stack[RTC_LDS_STACK * RTC_WAVE];
     __shared__ double parked[PK_COUNT * RTC_WAVE];
     const unsigned lane = threadIdx.x;
     int *const stack = &bvh_stack[lane];  // [entry][lane]: conflict free
     lds_f64 *const pk = (lds_f64 *)parked + lane;
     int deep_stack[RTC_BVH_STACK - RTC_LDS_STACK];  // scratch memory: entries beyond the LDS part (rare)
-    const unsigned tile = blockIdx.x;
-    const unsigned tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
-    const unsigned x = tx * 8u + (lane & 7u);
-    const unsigned l = ty * 8u + (lane >> 3);
-    const bool in_image = x < s.cam.hsize && l < prm.local_rows;
-    const unsigned y = canvas_row(prm, l);
-    // camera.rs:72,78: rows 0..vsize-1 and columns 0..hsize-1 (exclusive) -- Q1
-    bool alive = in_image && (x + 1u < s.cam.hsize) && (y + 1u < s.cam.vsize);
     const bool use_bvh = prm.use_bvh != 0;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    const unsigned n_tiles = prm.tiles_x * prm.tiles_y;
 
     Counters cnt;
     if (STATS)
         for (int i = 0; i < ST_COUNT; i++) cnt.c[i] = 0;
 
+    // ---- lane <-> pixel binding.  The grid is persistent: a wave draws 8x8 pixel tiles from a device-wide
+    // counter and hands the tile's pixels to lanes AS THEY BECOME FREE, so a lane whose pixel needs a deep ray
+    // tree does not idle the other 63 (camera.rs:72-85 parallelises over rows with the same dynamic flavour).
+    bool alive = false;
+    unsigned pix = 0;               // tile * 64 + position in tile
+    // wave-uniform: unassigned pixels of the tile in hand.  Wave b starts with tile b (no counter traffic while
+    // the grid starts up); tiles from prm.dyn_base (= the grid size) on are drawn from the counters.
+    unsigned r_next = blockIdx.x * 64u, r_end = r_next + 64u;
+    const unsigned n_dynamic = PERSISTENT ? n_tiles - prm.dyn_base : 0u;
+    unsigned shard = blockIdx.x % RTC_SHARDS, shards_tried = 0;
+    bool exhausted = n_dynamic == 0u;  // wave-uniform: every counter ran past its last tile
+
     // ---- path state ----
-    park3(pk, PK_COLOR, mk(0., 0., 0.));
-    pk[PK_W * RTC_WAVE] = 1.;
     double mult = 1.;  // STATS only: how many times the reference traces this ray (Q3)
-    int remaining = (int)prm.depth;
+    int remaining = 0;
     Pending pend[RTC_MAX_DEPTH_STACK];
     int sp = 0;
     int rays = 0;
@@ -664,23 +680,110 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     int li = 0;
     unsigned su = 0, sv = 0, unshadowed = 0;
 
-    if (alive) {
-        // Camera::ray_for_pixel, camera.rs:41-59
-        const double xo = ((double)x + 0.5) * s.cam.pixel_size;
-        const double yo = ((double)y + 0.5) * s.cam.pixel_size;
-        const double wx = s.cam.half_width - xo;
-        const double wy = s.cam.half_height - yo;
-        const V3 pixel = xf_point(s.cam.inv, mk(wx, wy, -1.));
-        ray.o = xf_point(s.cam.inv, mk(0., 0., 0.));
-        ray.d = normalize(pixel - ray.o);
-        CNT(ST_PRIMARY, 1);
-        rays = 1;
-    }
-
-    const DLeaf *__restrict__ const lin = use_bvh ? s.leaves : s.leaves_all;
+    // The scene tables are immutable during the launch: reading the lockstep list through the constant address
+    // space keeps its loads on the scalar cache even though this kernel also stores (pixels, tile counter).
+    typedef const __attribute__((address_space(4))) DLeaf *const_leaf_ptr;
+    const const_leaf_ptr lin = (const_leaf_ptr)(use_bvh ? s.leaves : s.leaves_all);
     const int n_lin = use_bvh ? s.n_unbounded : s.n_prims;
 
-    while (alive) {
+    // binds this lane to pixel `pix`: primary ray and a fresh path state, or a black pixel (Q1 / tile padding)
+    auto init_pixel = [&]() {
+            const unsigned tile = pix >> 6, q = pix & 63u;
+            const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
+            const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
+            const unsigned y = canvas_row(prm, l);
+            if (x < s.cam.hsize && l < prm.local_rows) {
+                // camera.rs:72,78: rows 0..vsize-1 and columns 0..hsize-1 (exclusive) -- Q1
+                if ((x + 1u < s.cam.hsize) && (y + 1u < s.cam.vsize)) {
+                    // Camera::ray_for_pixel, camera.rs:41-59
+                    const double xo = ((double)x + 0.5) * s.cam.pixel_size;
+                    const double yo = ((double)y + 0.5) * s.cam.pixel_size;
+                    const double wx = s.cam.half_width - xo;
+                    const double wy = s.cam.half_height - yo;
+                    const V3 pixel = xf_point(s.cam.inv, mk(wx, wy, -1.));
+                    ray.o = xf_point(s.cam.inv, mk(0., 0., 0.));
+                    ray.d = normalize(pixel - ray.o);
+                    park3(pk, PK_COLOR, mk(0., 0., 0.));
+                    pk[PK_W * RTC_WAVE] = 1.;
+                    mult = 1.;
+                    remaining = (int)prm.depth;
+                    sp = 0;
+                    rays = 1;
+                    T.mode = MODE_CLOSEST;
+                    T.lim = inf, T.prim = -1;
+                    CNT(ST_PRIMARY, 1);
+                    alive = true;
+                } else {
+                    double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
+                    px[0] = 0., px[1] = 0., px[2] = 0.;  // Canvas::new: black
+                }
+            }
+    };
+    // the pixel is finished: Canvas::write_pixel (camera.rs:87-91)
+    auto write_pixel = [&]() {
+        const unsigned tile = pix >> 6, q = pix & 63u;
+        const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
+        const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
+        const V3 color = unpark3(pk, PK_COLOR);
+        double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
+        px[0] = color.x, px[1] = color.y, px[2] = color.z;
+    };
+    bool rendered = false;
+    if (!PERSISTENT) {
+        // static schedule: workgroup b renders tile b and nothing else
+        pix = blockIdx.x * 64u + lane;
+        init_pixel();
+        rendered = alive;
+    }
+
+    for (;;) {
+        // =====================================================================================
+        // refill: free lanes take the next pixels (wave-uniform control flow)
+        // =====================================================================================
+        {
+            unsigned long long dead = __ballot(!alive);
+            if (PERSISTENT && ((unsigned)__popcll(dead) >= prm.refill_min || dead == ~0ull)) {
+                for (;;) {
+                    if (r_next == r_end) {
+                        if (exhausted) break;
+                        // one tile per request from RTC_SHARDS counters (one 128-byte line each): dynamic tile d
+                        // belongs to shard d % RTC_SHARDS, a wave starts at its own shard and moves on to the
+                        // next one when a shard runs dry, so no word sees more than 1/RTC_SHARDS of the traffic
+                        unsigned t = n_tiles;
+                        while (shards_tried < RTC_SHARDS) {
+                            unsigned k = 0;
+                            if (lane == 0) k = atomicAdd(work + shard * 32u, 1u);
+                            k = __builtin_amdgcn_readfirstlane(k);
+                            const unsigned d = k * RTC_SHARDS + shard;
+                            if (d < n_dynamic) {
+                                t = prm.dyn_base + d;
+                                break;
+                            }
+                            shard = (shard + 1u) % RTC_SHARDS;
+                            shards_tried++;
+                        }
+                        if (t >= n_tiles) {
+                            exhausted = true;
+                            break;
+                        }
+                        r_next = t * 64u, r_end = r_next + 64u;
+                    }
+                    dead = __ballot(!alive);
+                    if (!dead) break;
+                    const unsigned avail = r_end - r_next;
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(dead >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)dead, 0u));
+                    if (!alive && rank < avail) {
+                        pix = r_next + rank;
+                        init_pixel();
+                    }
+                    const unsigned taken = (unsigned)__popcll(dead);
+                    r_next += taken < avail ? taken : avail;
+                }
+            }
+            if (__ballot(alive) == 0ull) break;  // no pixel in flight and none left: the wave is done
+        }
+        if (alive) {
         // =====================================================================================
         // World::intersect (world.rs:176-186) without materialising the list
         // =====================================================================================
@@ -691,7 +794,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             // ---- phase 1: lockstep walk over the always-tested list (i, L.* are wave-uniform) ----
             int u_cache = -1;
             for (int i = 0; i < n_lin; i++) {
-                const DLeaf &L = lin[i];
+                const __attribute__((address_space(4))) DLeaf &L = lin[i];
                 Ray r = ray;
                 if (GROUPS && L.anc_len > 0) {
                     if (L.anc_id != u_cache) {
@@ -988,13 +1091,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             park3(pk, PK_COLOR, mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.));
             alive = false;
         }
+        if (PERSISTENT && !alive) write_pixel();  // the lane is free for the next pixel
+        }  // if (alive)
     }
+    if (!PERSISTENT && rendered) write_pixel();  // the whole tile at once
 
-    if (in_image) {
-        const V3 color = unpark3(pk, PK_COLOR);
-        double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
-        px[0] = color.x, px[1] = color.y, px[2] = color.z;
-    }
     if (STATS) {
         for (int i = 0; i < ST_COUNT; i++) {
             unsigned long long v = cnt.c[i];
@@ -1004,22 +1105,58 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     }
 }
 
-int launch_render(const DScene &scene, const DRenderParams &params, double *d_rgb, uint64_t *d_stats,
-                  bool collect_stats, void *stream) {
+template <class K>
+static unsigned resident_waves(K kernel, unsigned n_cu) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RTC_WAVE, 0) != hipSuccess || per_cu <= 0)
+        per_cu = 4 * RTC_MIN_WAVES;
+    return n_cu * (unsigned)per_cu;
+}
+
+template <bool STATS, bool GROUPS, bool PATTERNS>
+static void launch_variant(const DScene &scene, DRenderParams &params, double *d_rgb, unsigned long long *ds,
+                           unsigned *d_work, unsigned n_cu, hipStream_t st) {
+    const unsigned tiles = params.tiles_x * params.tiles_y;
+    // schedule: static = one workgroup per tile, the hardware dispatcher balances (best while the lanes of a
+    // tile finish together); persistent = resident waves draw tiles from the counters and refill free lanes
+    // (best when some pixels grow ray trees thousands of rays deep)
+    if (params.persistent) {
+        static unsigned cap = 0;
+        if (!cap) cap = resident_waves(k_render<STATS, GROUPS, PATTERNS, true>, n_cu);
+        const unsigned waves = tiles < cap ? tiles : cap;
+        static const unsigned refill_env = getenv("RTC_REFILL_MIN") ? (unsigned)atoi(getenv("RTC_REFILL_MIN")) : 0u;
+        params.refill_min = refill_env ? refill_env : RTC_REFILL_MIN;
+        params.dyn_base = waves;  // wave b renders tile b first
+        hipLaunchKernelGGL((k_render<STATS, GROUPS, PATTERNS, true>), dim3(waves), dim3(RTC_WAVE), 0, st, scene, params,
+                           d_rgb, ds, d_work);
+    } else {
+        params.refill_min = RTC_WAVE;
+        params.dyn_base = tiles;
+        hipLaunchKernelGGL((k_render<STATS, GROUPS, PATTERNS, false>), dim3(tiles), dim3(RTC_WAVE), 0, st, scene, params,
+                           d_rgb, ds, d_work);
+    }
+}
+
+int launch_render(const DScene &scene, const DRenderParams &params_in, double *d_rgb, uint64_t *d_stats,
+                  unsigned *d_work, unsigned n_cu, bool collect_stats, void *stream) {
+    DRenderParams params = params_in;
     const unsigned tiles = params.tiles_x * params.tiles_y;
     if (tiles == 0) return RTC_OK;
     hipStream_t st = (hipStream_t)stream;
-    static const unsigned lds_pad = getenv("RTC_LDS_PAD") ? (unsigned)atoi(getenv("RTC_LDS_PAD")) : 0u;  // occupancy experiments
+    // the tile counters of the persistent grid start at zero for every launch
+    if (params.persistent && hipMemsetAsync(d_work, 0, RTC_SHARDS * 128u, st) != hipSuccess) {
+        set_error("hipMemsetAsync(work counter) failed");
+        return RTC_ERR_HIP;
+    }
     unsigned long long *ds = (unsigned long long *)d_stats;
-    const dim3 grid(tiles), block(RTC_WAVE);
     if (collect_stats)
-        hipLaunchKernelGGL((k_render<true, true, true>), grid, block, lds_pad, st, scene, params, d_rgb, ds);
+        launch_variant<true, true, true>(scene, params, d_rgb, ds, d_work, n_cu, st);
     else if (scene.any_pattern)
-        hipLaunchKernelGGL((k_render<false, true, true>), grid, block, lds_pad, st, scene, params, d_rgb, ds);
+        launch_variant<false, true, true>(scene, params, d_rgb, ds, d_work, n_cu, st);
     else if (scene.any_group)
-        hipLaunchKernelGGL((k_render<false, true, false>), grid, block, lds_pad, st, scene, params, d_rgb, ds);
+        launch_variant<false, true, false>(scene, params, d_rgb, ds, d_work, n_cu, st);
     else
-        hipLaunchKernelGGL((k_render<false, false, false>), grid, block, lds_pad, st, scene, params, d_rgb, ds);
+        launch_variant<false, false, false>(scene, params, d_rgb, ds, d_work, n_cu, st);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("kernel launch failed: %s", hipGetErrorString(e));

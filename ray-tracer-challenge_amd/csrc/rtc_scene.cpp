@@ -42,6 +42,7 @@ void Scene::release_device() {
     device_allocs.clear();
     ev_start = ev_stop = nullptr;
     d_stats = nullptr;
+    d_work = nullptr;
     device_bytes = 0;
 }
 
@@ -315,6 +316,9 @@ int Scene::flatten() {
             }
         }
     }
+    n_transparent_prims = 0;
+    for (const DPrim &p : prims)
+        if (dmaterials[p.material].transparency != 0.) n_transparent_prims++;
     for (size_t i = 0; i < prims.size(); i++) {
         bool ok = prim_bounded[i];
         if (ok)
@@ -634,6 +638,18 @@ int Scene::upload(int dev) {
     const uint64_t *dst = nullptr;
     if ((rc = upload_vec(*this, zeros, dst))) return rc;
     d_stats = const_cast<uint64_t *>(dst);
+    {
+        std::vector<unsigned> wz(8 * 32, 0u);  // RTC_SHARDS counters, one 128-byte line each
+        const unsigned *dw = nullptr;
+        if ((rc = upload_vec(*this, wz, dw))) return rc;
+        d_work = const_cast<unsigned *>(dw);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            set_error("hipGetDeviceProperties failed");
+            return RTC_ERR_HIP;
+        }
+        max_waves = (unsigned)prop.multiProcessorCount;  // CU count; the launcher multiplies by the occupancy
+    }
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
         set_error("hipEventCreate failed");

@@ -71,6 +71,7 @@ struct Scene {
     std::vector<uint8_t> prim_bounded;
     std::vector<int32_t> prim_anc_id;  // ancestor-chain identity per primitive (-1: top level)
     uint32_t bvh_max_depth = 0, bvh_max_leaf = 0;
+    uint32_t n_transparent_prims = 0;
     int32_t root_ref = 0;
     double root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 
@@ -79,6 +80,8 @@ struct Scene {
     std::vector<void *> device_allocs;
     uint64_t device_bytes = 0;
     uint64_t *d_stats = nullptr;  // ST_COUNT counters
+    unsigned *d_work = nullptr;   // tile counters of the persistent render grid (8 x 128 B, zeroed per launch)
+    unsigned max_waves = 0;       // CU count of the device (persistent grid = CUs x resident waves per CU)
     void *ev_start = nullptr, *ev_stop = nullptr;
     rtc_stats last_stats{};
     bool have_last_stats = false;
@@ -94,7 +97,7 @@ struct Scene {
 
 // kernels (rtc_kernels.hip)
 int launch_render(const DScene &scene, const DRenderParams &params, double *d_rgb, uint64_t *d_stats,
-                  bool collect_stats, void *stream);
+                  unsigned *d_work, unsigned n_cu, bool collect_stats, void *stream);
 
 // tiling helpers shared by the API and the launcher
 uint32_t local_rows(uint32_t vsize, uint32_t tile_rows, uint32_t tile_index, uint32_t tile_count);

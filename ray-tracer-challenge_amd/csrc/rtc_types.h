@@ -131,6 +131,9 @@ struct DRenderParams {
     uint32_t local_rows;  // rows owned by this rank (compact output)
     uint32_t use_bvh;     // resolved: 1 = BVH + unbounded list, 0 = brute force over all prims
     uint32_t tiles_x, tiles_y;  // 8x8 pixel tiles covering hsize x local_rows
+    uint32_t persistent;        // 1: persistent grid + lane refill, 0: one workgroup per tile
+    uint32_t dyn_base;          // first tile handed out through the device-wide counters (= grid size)
+    uint32_t refill_min;        // free lanes a wave waits for before it assigns new pixels (1..64)
 };
 
 // device-side counters, one uint64 each (index constants)

@@ -1,0 +1,16 @@
+import importlib, sys, time
+sys.path.insert(0, '.')
+rtc = importlib.import_module("ray-tracer-challenge_amd")
+n, w, h = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+t = time.time(); world, cam = rtc.stress_scene.build(n, w, h); print("build %.1fs" % (time.time() - t), flush=True)
+t = time.time(); sc = cam.compile(world, device=0); print("commit %.1fs" % (time.time() - t), sc.info(), flush=True)
+for mode in sys.argv[4:]:
+    kw = {}
+    if mode.startswith("tile"):
+        kw = dict(tile_rows=8, tile_index=int(mode[4:]), tile_count=(h + 7) // 8)
+        for ub in (1, 2):
+            t = time.time(); img = sc.render(use_bvh=ub, collect_stats=True, **kw)
+            print(mode, "use_bvh", ub, "%.2fs" % (time.time() - t), "kernel_ms", sc.last_stats["kernel_ms"], "sum", float(abs(img).sum()), {k: sc.last_stats[k] for k in ("primary_rays", "shadow_rays", "secondary_rays", "container_passes", "overflow", "box_tests")}, flush=True)
+    else:
+        t = time.time(); img = sc.render(collect_stats=True)
+        print("full", "%.2fs" % (time.time() - t), "kernel_ms", sc.last_stats["kernel_ms"], {k: sc.last_stats[k] for k in ("primary_rays", "shadow_rays", "secondary_rays", "container_passes", "overflow", "box_tests", "prim_tests")}, flush=True)
