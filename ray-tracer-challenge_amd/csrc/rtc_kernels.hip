@@ -35,7 +35,13 @@ namespace rtc {
 #define RTC_BVH_STACK 32
 #define RTC_MAX_DEPTH_STACK 8
 #define RTC_MAX_RAYS_PER_PIXEL 65536
+#define RTC_NO_NODE ((int)0x80000000)  // "no node in hand": the next step pops the stack
+#define RTC_STEPS_PER_CHECK 4         // traversal steps between two looks at the wave's occupancy
+#define RTC_NODES_PER_STEP 4          // BVH nodes one step may descend through
 #define RTC_SHARDS 8u  // tile counters of the persistent grid
+#ifndef RTC_STAY_MIN
+#define RTC_STAY_MIN 32  // lanes inside a pass below which the wave leaves the traversal to serve idle lanes
+#endif
 #ifndef RTC_REFILL_MIN
 #define RTC_REFILL_MIN 1  // free lanes needed before a wave assigns new pixels
 #endif
@@ -475,13 +481,13 @@ DEV double schlick(double n1, double n2, V3 eye, V3 normal) {
 // Slab test of a padded world-space box.  This is the build's own culling arithmetic, not reference
 // arithmetic: it uses FMA and an approximate reciprocal; the 1e-6 relative padding of the boxes (host) is ten
 // orders of magnitude above its rounding error.  fmin/fmax drop NaNs, which keeps the test conservative.
-DEV bool slab(const double *bmin, const double *bmax, const V3 &inv_d, const V3 &oi, double lo, double hi,
-              double &tnear) {
-    double t1 = fma(bmin[0], inv_d.x, oi.x), t2 = fma(bmax[0], inv_d.x, oi.x);
+template <class F>
+DEV bool slab(const F *bmin, const F *bmax, const V3 &inv_d, const V3 &oi, double lo, double hi, double &tnear) {
+    double t1 = fma((double)bmin[0], inv_d.x, oi.x), t2 = fma((double)bmax[0], inv_d.x, oi.x);
     double tn = fmin(t1, t2), tf = fmax(t1, t2);
-    t1 = fma(bmin[1], inv_d.y, oi.y), t2 = fma(bmax[1], inv_d.y, oi.y);
+    t1 = fma((double)bmin[1], inv_d.y, oi.y), t2 = fma((double)bmax[1], inv_d.y, oi.y);
     tn = fmax(tn, fmin(t1, t2)), tf = fmin(tf, fmax(t1, t2));
-    t1 = fma(bmin[2], inv_d.z, oi.z), t2 = fma(bmax[2], inv_d.z, oi.z);
+    t1 = fma((double)bmin[2], inv_d.z, oi.z), t2 = fma((double)bmax[2], inv_d.z, oi.z);
     tn = fmax(tn, fmin(t1, t2)), tf = fmin(tf, fmax(t1, t2));
     tnear = tn;
     return tn <= tf && tn <= hi && tf >= lo;
@@ -675,6 +681,12 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     T.lim = inf, T.prim = -1, T.a = T.b = 0.;
     T.c_best_prim = -1, T.c_hit_open = 0;
     T.n = 0, T.last = 0.;
+    // ---- BVH traversal state of the pass in flight (resumable) ----
+    bool in_pass = false;
+    int pos = 0, end = 0, sb = 0, cur = RTC_NO_NODE;
+    V3 inv_d = mk(0., 0., 0.), oi = mk(0., 0., 0.);
+    int cache_id = -1;  // ancestor chain the cached ray is expressed in (GROUPS)
+    Ray cache_ray = ray;
     // ---- shading context (valid from the closest hit until the last shadow ray of that hit) ----
     int h_prim = -1;
     int li = 0;
@@ -783,15 +795,16 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             }
             if (__ballot(alive) == 0ull) break;  // no pixel in flight and none left: the wave is done
         }
-        if (alive) {
         // =====================================================================================
-        // World::intersect (world.rs:176-186) without materialising the list
+        // World::intersect (world.rs:176-186) without materialising the list.
+        // (A) lanes holding a fresh ray start its pass; (B) the BVH traversal advances in steps for every lane
+        // that is inside a pass; (C) lanes whose pass is complete run the state machine.  A traversal is
+        // resumable: its state (node in hand, leaf run, stack) lives in registers / LDS across (C), so the wave
+        // can leave (B) to serve finished lanes while long rays are still on their way, and re-enter.
         // =====================================================================================
-        const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
-        int cache_id = -1;  // ancestor chain the cached ray is expressed in (GROUPS)
-        Ray cache_ray = ray;
-        {
-            // ---- phase 1: lockstep walk over the always-tested list (i, L.* are wave-uniform) ----
+        if (alive && !in_pass) {
+            // ---- (A) phase 1: lockstep walk over the always-tested list (i, L.* are wave-uniform) ----
+            const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
             int u_cache = -1;
             for (int i = 0; i < n_lin; i++) {
                 const __attribute__((address_space(4))) DLeaf &L = lin[i];
@@ -810,15 +823,33 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     isect_leaf(L, r, T);
                 }
             }
-            cache_id = u_cache;
+            if (GROUPS) cache_id = u_cache;
+            if (use_bvh && s.n_bounded > 0 && !(any_hit && T.prim >= 0)) {
+                // ---- phase 2 set-up: ordered BVH traversal, leaves tested as they are reached ----
+                inv_d = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
+                oi = mk(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z);
+                pos = 0, end = 0, sb = 0;
+                double tn;
+                CNT(ST_BOX, 1);
+                if (slab(s.root_min, s.root_max, inv_d, oi, (T.mode == MODE_CONTAINER) ? -inf : 0., T.lim, tn)) {
+                    cur = s.root_ref;
+                    in_pass = true;
+                }
+            }
         }
-        if (use_bvh && s.n_bounded > 0 && !(any_hit && T.prim >= 0)) {
-            // ---- phase 2: ordered BVH traversal, leaves tested as they are reached ----
-            const double lo = (T.mode == MODE_CONTAINER) ? -inf : 0.;
-            const V3 inv_d = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
-            const V3 oi = mk(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z);
-            int pos = 0, end = 0, sb = 0;
-            bool root_pending = true;
+        // ---- (B) traversal steps ----
+        for (;;) {
+            const unsigned long long act = __ballot(alive && in_pass);
+            if (!act) break;
+            if (PERSISTENT && (unsigned)__popcll(act) < prm.stay_min) {
+                // few lanes are still inside a pass: leave if some lane could use the time (finished pass, or a
+                // free lane that can take a new pixel)
+                unsigned long long idle = __ballot(alive && !in_pass);
+                const unsigned long long dead = __ballot(!alive);
+                if (!(exhausted && r_next == r_end) && (unsigned)__popcll(dead) >= prm.refill_min) idle |= dead;
+                if (idle) break;
+            }
+            if (alive && in_pass) {
 #define RTC_PUSH(v)                                                 \
     do {                                                            \
         if (sb < RTC_LDS_STACK)                                     \
@@ -833,70 +864,76 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         (v) = (sb < RTC_LDS_STACK) ? stack[sb * RTC_WAVE]                                            \
                                    : deep_stack[(sb < RTC_BVH_STACK ? sb : RTC_BVH_STACK - 1) - RTC_LDS_STACK]; \
     } while (0)
-            for (;;) {
-                if (pos < end) {
-                    const DLeaf &L = s.leaves[pos++];
-                    // Ray::transform down the ancestor chain, root first (shape.rs:2035).  Primitives of one
-                    // group share it: the ray in group space is cached per lane.
-                    Ray r = ray;
-                    if (GROUPS && L.anc_len > 0) {
-                        if (L.anc_id != cache_id) {
-                            cache_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
-                            cache_id = L.anc_id;
-                            CNT(ST_XFORM, L.anc_len);
+                const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
+                const double lo = (T.mode == MODE_CONTAINER) ? -inf : 0.;
+                for (int step = 0; step < RTC_STEPS_PER_CHECK && in_pass; step++) {
+                    if (pos < end) {
+                        const DLeaf &L = s.leaves[pos++];
+                        // Ray::transform down the ancestor chain, root first (shape.rs:2035).  Primitives of one
+                        // group share it: the ray in group space is cached per lane.
+                        Ray r = ray;
+                        if (GROUPS && L.anc_len > 0) {
+                            if (L.anc_id != cache_id) {
+                                cache_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
+                                cache_id = L.anc_id;
+                                CNT(ST_XFORM, L.anc_len);
+                            }
+                            r = cache_ray;
                         }
-                        r = cache_ray;
+                        CNT(ST_XFORM, L.type < PT_TRIANGLE ? 1 : 0);
+                        CNT(ST_PRIM0 + L.type, 1);
+                        isect_leaf(L, r, T);
+                        if (any_hit && T.prim >= 0) in_pass = false;
+                        continue;
                     }
-                    CNT(ST_XFORM, L.type < PT_TRIANGLE ? 1 : 0);
-                    CNT(ST_PRIM0 + L.type, 1);
-                    isect_leaf(L, r, T);
-                    if (any_hit && T.prim >= 0) break;
-                    continue;
-                }
-                // ---- next leaf ----
-                int ref;
-                if (root_pending) {
-                    root_pending = false;
-                    double tn;
-                    CNT(ST_BOX, 1);
-                    if (!slab(s.root_min, s.root_max, inv_d, oi, lo, T.lim, tn)) break;
-                    ref = s.root_ref;
-                } else if (sb > 0) {
-                    RTC_POP(ref);
-                } else {
-                    break;
-                }
-                bool finished = false;
-                while (ref >= 0) {
-                    const DBvhNode &n = s.bvh[ref];
-                    double tl, tr;
-                    CNT(ST_BOX, 2);
-                    const bool hl = slab(n.lmin, n.lmax, inv_d, oi, lo, T.lim, tl);
-                    const bool hr = slab(n.rmin, n.rmax, inv_d, oi, lo, T.lim, tr);
-                    const int cl = n.left, cr = n.right;
-                    if (hl && hr) {
-                        const bool left_first = tl <= tr;
-                        RTC_PUSH(left_first ? cr : cl);
-                        ref = left_first ? cl : cr;
-                    } else if (hl) {
-                        ref = cl;
-                    } else if (hr) {
-                        ref = cr;
-                    } else if (sb > 0) {
-                        RTC_POP(ref);
+                    // ---- the node in hand, or the next one from the stack ----
+                    int ref = cur;
+                    if (ref == RTC_NO_NODE) {
+                        if (sb > 0) {
+                            RTC_POP(ref);
+                        } else {
+                            in_pass = false;
+                            continue;
+                        }
+                    }
+                    // descend until a leaf is reached (bounded: the check above runs again after a few nodes)
+                    for (int d = 0; d < RTC_NODES_PER_STEP && ref >= 0; d++) {
+                        const DBvhNode &n = s.bvh[ref];
+                        double tl, tr;
+                        CNT(ST_BOX, 2);
+                        const bool hl = slab(n.lmin, n.lmax, inv_d, oi, lo, T.lim, tl);
+                        const bool hr = slab(n.rmin, n.rmax, inv_d, oi, lo, T.lim, tr);
+                        const int cl = n.left, cr = n.right;
+                        if (hl && hr) {
+                            const bool left_first = tl <= tr;
+                            RTC_PUSH(left_first ? cr : cl);
+                            ref = left_first ? cl : cr;
+                        } else if (hl) {
+                            ref = cl;
+                        } else if (hr) {
+                            ref = cr;
+                        } else if (sb > 0) {
+                            RTC_POP(ref);
+                        } else {
+                            in_pass = false;
+                            ref = RTC_NO_NODE;
+                            break;
+                        }
+                    }
+                    if (ref >= 0 || ref == RTC_NO_NODE) {
+                        cur = ref;  // still an internal node (or finished): carry on at the next step
                     } else {
-                        finished = true;
-                        break;
+                        const int code = ~ref;
+                        pos = code >> 3;
+                        end = pos + (code & 7) + 1;
+                        cur = RTC_NO_NODE;
                     }
                 }
-                if (finished) break;
-                const int code = ~ref;
-                pos = code >> 3;
-                end = pos + (code & 7) + 1;
-            }
 #undef RTC_PUSH
 #undef RTC_POP
+            }
         }
+        if (alive && !in_pass) {
         // (the parked values are re-read from LDS after a pass; the compiler does not carry them across it --
         // checked in the ISA: no launder is needed, and an asm barrier here would cost the scalar loads above)
 
@@ -1127,6 +1164,8 @@ static void launch_variant(const DScene &scene, DRenderParams &params, double *d
         static const unsigned refill_env = getenv("RTC_REFILL_MIN") ? (unsigned)atoi(getenv("RTC_REFILL_MIN")) : 0u;
         params.refill_min = refill_env ? refill_env : RTC_REFILL_MIN;
         params.dyn_base = waves;  // wave b renders tile b first
+        static const unsigned stay_env = getenv("RTC_STAY_MIN") ? (unsigned)atoi(getenv("RTC_STAY_MIN")) : 0u;
+        params.stay_min = stay_env ? stay_env : RTC_STAY_MIN;
         hipLaunchKernelGGL((k_render<STATS, GROUPS, PATTERNS, true>), dim3(waves), dim3(RTC_WAVE), 0, st, scene, params,
                            d_rgb, ds, d_work);
     } else {

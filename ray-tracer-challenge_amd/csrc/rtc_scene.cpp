@@ -461,6 +461,18 @@ struct Builder {
 
 }  // namespace
 
+// f64 -> f32 with the rounding directed away from the box interior
+static float f32_down(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+static float f32_up(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+
 void Scene::build_bvh() {
     bvh.clear(), bvh_prims.clear();
     bvh_max_depth = 0, bvh_max_leaf = 0;
@@ -515,8 +527,8 @@ void Scene::build_bvh() {
             const BuildNode &l = b.nodes[n.left], &r = b.nodes[n.right];
             DBvhNode d{};
             for (int k = 0; k < 3; k++) {
-                d.lmin[k] = l.b.lo[k], d.lmax[k] = l.b.hi[k];
-                d.rmin[k] = r.b.lo[k], d.rmax[k] = r.b.hi[k];
+                d.lmin[k] = f32_down(l.b.lo[k]), d.lmax[k] = f32_up(l.b.hi[k]);
+                d.rmin[k] = f32_down(r.b.lo[k]), d.rmax[k] = f32_up(r.b.hi[k]);
             }
             d.left = (l.left >= 0) ? new_index[n.left] : leaf_ref(l);
             d.right = (r.left >= 0) ? new_index[n.right] : leaf_ref(r);

@@ -6,8 +6,8 @@
 //   DPrim[]     one per leaf shape in depth-first (== reference traversal) order, 56 B
 //   DTri[]      triangle payloads (p1, e1, e2, n1..n3), 144 B
 //   DMaterial[] 88 B, DLight[] 136 B, DPattern[] 160 B
-//   DBvhNode[]  128 B internal nodes of the binary BVH over the bounded primitives (breadth-first order),
-//               each holding BOTH children's boxes
+//   DBvhNode[]  64 B internal nodes of the binary BVH over the bounded primitives (breadth-first order),
+//               each holding BOTH children's boxes in outward-rounded f32
 //   int prim_list[] unbounded primitives (tested for every ray) followed by the BVH leaves' primitive runs
 #pragma once
 #include <stdint.h>
@@ -85,15 +85,17 @@ struct DPattern {
     double inv[12];
 };
 
-// One per INTERNAL node of the binary BVH (128 B = one cache line pair): both children's padded world-space
-// boxes live in the parent so a traversal step costs a single fetch.  Child references: >= 0 is the index
-// of another internal node; < 0 encodes a leaf as ~((first << 3) | (count - 1)) with `first` an offset into
-// DScene::prim_list.
+// One per INTERNAL node of the binary BVH (64 B = half a cache line): both children's padded world-space boxes
+// live in the parent so a traversal step costs a single 64-byte fetch -- four 16-byte loads per lane; incoherent
+// rays pay one L1 tag look-up per lane per load, which is what bounds the traversal, so the boxes are stored
+// in f32, rounded OUTWARD (they are culling volumes of this build, not reference arithmetic; the slab test
+// itself runs in f64).  Child references: >= 0 is the index of another internal node; < 0 encodes a leaf as
+// ~((first << 3) | (count - 1)) with `first` an offset into DScene::prim_list / DScene::leaves.
 struct DBvhNode {
-    double lmin[3], lmax[3];
-    double rmin[3], rmax[3];
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
     int32_t left, right;
-    int32_t pad[6];
+    int32_t pad[2];
 };
 
 struct DCamera {
@@ -133,6 +135,7 @@ struct DRenderParams {
     uint32_t tiles_x, tiles_y;  // 8x8 pixel tiles covering hsize x local_rows
     uint32_t persistent;        // 1: persistent grid + lane refill, 0: one workgroup per tile
     uint32_t dyn_base;          // first tile handed out through the device-wide counters (= grid size)
+    uint32_t stay_min;          // lanes inside a pass below which a wave leaves the traversal loop (persistent)
     uint32_t refill_min;        // free lanes a wave waits for before it assigns new pixels (1..64)
 };
 

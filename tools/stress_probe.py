@@ -12,5 +12,5 @@ for mode in sys.argv[4:]:
             t = time.time(); img = sc.render(use_bvh=ub, collect_stats=True, **kw)
             print(mode, "use_bvh", ub, "%.2fs" % (time.time() - t), "kernel_ms", sc.last_stats["kernel_ms"], "sum", float(abs(img).sum()), {k: sc.last_stats[k] for k in ("primary_rays", "shadow_rays", "secondary_rays", "container_passes", "overflow", "box_tests")}, flush=True)
     else:
-        t = time.time(); img = sc.render(collect_stats=True)
-        print("full", "%.2fs" % (time.time() - t), "kernel_ms", sc.last_stats["kernel_ms"], {k: sc.last_stats[k] for k in ("primary_rays", "shadow_rays", "secondary_rays", "container_passes", "overflow", "box_tests", "prim_tests")}, flush=True)
+        t = time.time(); img = sc.render(collect_stats=("stats" in sys.argv))
+        print("full", "%.2fs" % (time.time() - t), "kernel_ms", sc.last_stats["kernel_ms"], {k: sc.last_stats.get(k) for k in ("primary_rays", "shadow_rays", "secondary_rays", "container_passes", "overflow", "box_tests", "prim_tests")}, flush=True)
