@@ -6,7 +6,7 @@ TAG=${1:-r1}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
+BENCH="python3 bench.py --no-cpu-baseline --no-extra $*"
 echo "== kernel trace + stats" | tee $OUT/log.txt
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH >> $OUT/log.txt 2>&1 || exit 1
 for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
@@ -14,6 +14,6 @@ for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
             "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   echo "== pmc $pass" | tee -a $OUT/log.txt
-  timeout -s KILL 120 rocprofv3 --pmc $pass -d $OUT/pmc_$name -o pmc -- $BENCH >> $OUT/log.txt 2>&1 || echo "pass failed: $pass" | tee -a $OUT/log.txt
+  timeout -s KILL 170 rocprofv3 --pmc $pass -d $OUT/pmc_$name -o pmc -- $BENCH >> $OUT/log.txt 2>&1 || echo "pass failed: $pass" | tee -a $OUT/log.txt
 done
 find $OUT -name '*.csv' | head -50
