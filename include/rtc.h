@@ -186,6 +186,53 @@ typedef struct rtc_scene_info {
 } rtc_scene_info;
 int rtc_scene_get_info(rtc_scene *scene, rtc_scene_info *out);
 
+/* The builder tree as the reference would hold it (World.objects and Group::children order), for loaders'
+ * callers and tests.  Items are numbered in insertion order. */
+typedef struct rtc_item_info {
+    int32_t kind;        /* 0 = group, 1 = analytic shape, 2 = run of triangles */
+    int32_t parent;      /* enclosing group's item index, -1 = member of World.objects */
+    int32_t shape_type;  /* rtc_shape_type (kind 1) */
+    int32_t material_id; /* -1 = none */
+    uint32_t n_children; /* kind 0 */
+    uint32_t n_triangles; /* kind 2 */
+    int32_t closed;
+    int32_t smooth;      /* kind 2: SmoothTriangle run */
+    double minimum, maximum;
+    double transform[16];
+} rtc_item_info;
+typedef struct rtc_light_info {
+    int32_t is_area;
+    uint32_t usteps, vsteps;
+    double position[3], intensity[3];
+    double corner[3], uvec[3], vvec[3]; /* area lights: per-cell vectors (light.rs:80-104) */
+} rtc_light_info;
+uint32_t rtc_scene_item_count(rtc_scene *scene);
+int rtc_scene_get_item(rtc_scene *scene, uint32_t item, rtc_item_info *out);
+uint32_t rtc_scene_child_count(rtc_scene *scene, int32_t parent); /* parent = -1: World.objects */
+int rtc_scene_get_child(rtc_scene *scene, int32_t parent, uint32_t k, uint32_t *out_item);
+int rtc_scene_get_material(rtc_scene *scene, uint32_t material_id, rtc_material *out);
+int rtc_scene_get_triangles(rtc_scene *scene, uint32_t item, uint32_t first, uint32_t n, double *points,
+                            double *normals); /* 9 doubles per triangle each; normals may be NULL */
+int rtc_scene_get_light(rtc_scene *scene, uint32_t index, rtc_light_info *out);
+int rtc_scene_get_camera(rtc_scene *scene, uint32_t *hsize, uint32_t *vsize, double *field_of_view, double view[16]);
+
+/* ---- callers either side of the path (host only) ----
+ * parse_scene(&str) -> Scene (parse_scene/src/lib.rs:735-784): builds an UNCOMMITTED scene from YAML text.
+ * base_dir resolves relative `obj` file names (may be NULL); width/height != 0 override the camera's size (the
+ * reference has no such override: BASELINE.json's configs render the sample scenes at other resolutions).
+ * Errors: RTC_ERR_PARSE (ParseError / ParserError, text in rtc_last_error()), RTC_ERR_IO. */
+int rtc_scene_load_yaml(const char *yaml_text, const char *base_dir, uint32_t width, uint32_t height, rtc_scene **out);
+int rtc_scene_load_yaml_file(const char *path, uint32_t width, uint32_t height, rtc_scene **out);
+/* parse_obj_string(text, Some(material), Some(transformation)) (obj_file/src/lib.rs:40-230): adds the OBJ's default
+ * group (and its named child groups) to the scene.  material_id < 0 = Material::default(). */
+typedef struct rtc_obj_info {
+    uint32_t ignored_lines, vertices, normals, triangles, groups;
+} rtc_obj_info;
+int rtc_scene_add_obj(rtc_scene *scene, const char *obj_text, const double transform[16], int32_t material_id,
+                      rtc_obj_info *info);
+/* Canvas::to_ppm (canvas.rs:44-89): P3 text of a vsize x hsize x 3 f64 canvas.  out == NULL queries the size. */
+int rtc_canvas_to_ppm(const double *rgb, uint32_t hsize, uint32_t vsize, char *out, size_t cap, size_t *needed);
+
 #ifdef __cplusplus
 }
 #endif

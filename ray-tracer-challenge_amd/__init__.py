@@ -6,9 +6,9 @@ include/rtc.h); this package is the thin host-side mirror.  There is no CPU rend
 from . import _native, parallel, stress_scene
 from ._native import NonInvertibleMatrix, RtcError
 from .api import (AreaLight, BlendedPattern, Camera, Canvas, CheckerPattern, CompiledScene, Cone, Cube, Cylinder,
-                  GradientPattern, Group, Material, Matrix, Pattern, Plane, PointLight, RadialGradientPattern,
+                  GradientPattern, Group, Material, Matrix, NativeScene, Pattern, Plane, PointLight, RadialGradientPattern,
                   RingPattern, Shape, SmoothTriangle, SolidPattern, Sphere, StripePattern, TestPattern, Triangle,
-                  TriangleMesh, World, compute_view_transformation, glass_sphere)
+                  TriangleMesh, World, canvas_to_ppm, compute_view_transformation, glass_sphere)
 from .scene_yaml import (ParsedObj, ParseError, Scene, parse_obj_file, parse_obj_string, parse_scene,
                          parse_scene_file)
 

@@ -91,6 +91,22 @@ class SceneInfo(C.Structure):
         ("device_bytes", C.c_uint64)]
 
 
+class ItemInfo(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("parent", C.c_int32), ("shape_type", C.c_int32), ("material_id", C.c_int32),
+                ("n_children", C.c_uint32), ("n_triangles", C.c_uint32), ("closed", C.c_int32), ("smooth", C.c_int32),
+                ("minimum", C.c_double), ("maximum", C.c_double), ("transform", C.c_double * 16)]
+
+
+class LightInfo(C.Structure):
+    _fields_ = [("is_area", C.c_int32), ("usteps", C.c_uint32), ("vsteps", C.c_uint32),
+                ("position", C.c_double * 3), ("intensity", C.c_double * 3),
+                ("corner", C.c_double * 3), ("uvec", C.c_double * 3), ("vvec", C.c_double * 3)]
+
+
+class ObjInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("ignored_lines", "vertices", "normals", "triangles", "groups")]
+
+
 # every symbol include/rtc.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("rtc_last_error", C.c_char_p, []),
@@ -126,6 +142,19 @@ SYMBOLS = [
     ("rtc_local_row_map", C.c_int, [C.c_uint32] * 4 + [C.POINTER(C.c_uint32), C.c_uint32]),
     ("rtc_scene_last_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     ("rtc_scene_get_info", C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
+    ("rtc_scene_item_count", C.c_uint32, [C.c_void_p]),
+    ("rtc_scene_get_item", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(ItemInfo)]),
+    ("rtc_scene_child_count", C.c_uint32, [C.c_void_p, C.c_int32]),
+    ("rtc_scene_get_child", C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("rtc_scene_get_material", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Material)]),
+    ("rtc_scene_get_triangles", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, PD, PD]),
+    ("rtc_scene_get_light", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(LightInfo)]),
+    ("rtc_scene_get_camera", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_double), PD]),
+    ("rtc_scene_load_yaml", C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("rtc_scene_load_yaml_file", C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("rtc_scene_add_obj", C.c_int, [C.c_void_p, C.c_char_p, PD, C.c_int32, C.POINTER(ObjInfo)]),
+    ("rtc_canvas_to_ppm", C.c_int, [PD, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
 ]
 
 _lib = None

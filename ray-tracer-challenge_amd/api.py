@@ -432,6 +432,108 @@ class CompiledScene:
 
 # ----------------------------------------------------------------------------- camera.rs / canvas.rs
 
+class NativeScene(CompiledScene):
+    """An rtc_scene built by the C++ loaders (rtc_scene_load_yaml*, rtc_scene_add_obj) instead of api.py objects,
+    plus the builder-tree getters of include/rtc.h."""
+
+    def __init__(self, handle):
+        self.L = N.lib()
+        self.h = C.c_void_p(handle)
+        self.device = None
+        hs, vs = C.c_uint32(), C.c_uint32()
+        if self.L.rtc_scene_get_camera(self.h, C.byref(hs), C.byref(vs), None, None) == N.OK:
+            self.hsize, self.vsize = hs.value, vs.value
+
+    @staticmethod
+    def from_yaml(text: str, base_dir: Optional[str] = None, width: int = 0, height: int = 0) -> "NativeScene":
+        h = C.c_void_p()
+        N.check(N.lib().rtc_scene_load_yaml(text.encode(), base_dir.encode() if base_dir else None, width or 0,
+                                            height or 0, C.byref(h)))
+        return NativeScene(h.value)
+
+    @staticmethod
+    def from_yaml_file(path: str, width: int = 0, height: int = 0) -> "NativeScene":
+        h = C.c_void_p()
+        N.check(N.lib().rtc_scene_load_yaml_file(path.encode(), width or 0, height or 0, C.byref(h)))
+        return NativeScene(h.value)
+
+    @staticmethod
+    def from_obj(text: str, transformation: Optional[Matrix] = None, material_id: int = -1):
+        """parse_obj_string into an otherwise empty scene -> (scene, ObjInfo dict)"""
+        L = N.lib()
+        sc = NativeScene(L.rtc_scene_create())
+        info = N.ObjInfo()
+        t = _d16(transformation.m) if transformation is not None else None
+        N.check(L.rtc_scene_add_obj(sc.h, text.encode(), t, material_id, C.byref(info)))
+        return sc, {n: getattr(info, n) for n, _ in info._fields_}
+
+    def commit(self, device: int = 0):
+        N.check(self.L.rtc_scene_commit(self.h, device))
+        self.device = device
+        return self
+
+    # ---- builder tree ----
+    def item(self, idx: int) -> dict:
+        it = N.ItemInfo()
+        N.check(self.L.rtc_scene_get_item(self.h, idx, C.byref(it)))
+        d = {n: getattr(it, n) for n, _ in it._fields_ if n != "transform"}
+        d["transform"] = np.array(it.transform[:]).reshape(4, 4)
+        return d
+
+    def children(self, parent: int = -1) -> List[int]:
+        out = []
+        for k in range(self.L.rtc_scene_child_count(self.h, parent)):
+            v = C.c_uint32()
+            N.check(self.L.rtc_scene_get_child(self.h, parent, k, C.byref(v)))
+            out.append(v.value)
+        return out
+
+    def material(self, mid: int) -> Material:
+        m = N.Material()
+        N.check(self.L.rtc_scene_get_material(self.h, mid, C.byref(m)))
+        return Material(color=tuple(m.color), ambient=m.ambient, diffuse=m.diffuse, specular=m.specular,
+                        shininess=m.shininess, reflectivity=m.reflectivity, transparency=m.transparency,
+                        refractive_index=m.refractive_index, casts_shadow=bool(m.casts_shadow))
+
+    def triangles(self, idx: int):
+        it = self.item(idx)
+        n = it["n_triangles"]
+        pts = np.zeros((n, 9))
+        nrm = np.zeros((n, 9)) if it["smooth"] else None
+        N.check(self.L.rtc_scene_get_triangles(self.h, idx, 0, n, pts.ctypes.data_as(N.PD),
+                                               nrm.ctypes.data_as(N.PD) if nrm is not None else None))
+        return pts, nrm
+
+    def lights(self) -> List[dict]:
+        out = []
+        k = 0
+        while True:
+            li = N.LightInfo()
+            if self.L.rtc_scene_get_light(self.h, k, C.byref(li)) != N.OK:
+                break
+            out.append({n: (list(getattr(li, n)) if hasattr(getattr(li, n), "__len__") else getattr(li, n))
+                        for n, _ in li._fields_})
+            k += 1
+        return out
+
+    def camera(self) -> dict:
+        hs, vs, fov, view = C.c_uint32(), C.c_uint32(), C.c_double(), N.D16()
+        N.check(self.L.rtc_scene_get_camera(self.h, C.byref(hs), C.byref(vs), C.byref(fov), view))
+        return dict(hsize=hs.value, vsize=vs.value, field_of_view=fov.value, view=np.array(view[:]).reshape(4, 4))
+
+
+def canvas_to_ppm(pixels: np.ndarray) -> str:
+    """Canvas::to_ppm (canvas.rs:44-82) through rtc_canvas_to_ppm"""
+    px = np.ascontiguousarray(pixels, dtype=np.float64)
+    h, w = px.shape[0], px.shape[1]
+    need = C.c_size_t()
+    L = N.lib()
+    N.check(L.rtc_canvas_to_ppm(px.ctypes.data_as(N.PD), w, h, None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value + 1)
+    N.check(L.rtc_canvas_to_ppm(px.ctypes.data_as(N.PD), w, h, buf, need.value + 1, None))
+    return buf.raw[: need.value].decode("ascii")
+
+
 class Canvas:
     """canvas.rs:7-41 over a (height, width, 3) float64 array."""
 
@@ -441,6 +543,12 @@ class Canvas:
 
     def pixel_at(self, x, y):
         return self.pixels[y, x]
+
+    def write_pixel(self, x, y, color):
+        self.pixels[y, x] = color
+
+    def to_ppm(self) -> str:
+        return canvas_to_ppm(self.pixels)
 
 
 @dataclass

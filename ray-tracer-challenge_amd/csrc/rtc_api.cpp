@@ -455,4 +455,112 @@ int rtc_scene_get_info(rtc_scene *scene, rtc_scene_info *out) {
     return RTC_OK;
 }
 
+// ---- builder-tree introspection -----------------------------------------------------------------
+uint32_t rtc_scene_item_count(rtc_scene *scene) { return scene ? (uint32_t)scene->s.items.size() : 0u; }
+
+int rtc_scene_get_item(rtc_scene *scene, uint32_t item, rtc_item_info *out) {
+    CHECK_SCENE(scene)
+    if (!out || item >= scene->s.items.size()) {
+        set_error("item %u out of range", item);
+        return RTC_ERR_INVALID;
+    }
+    const Item &it = scene->s.items[item];
+    std::memset(out, 0, sizeof *out);
+    out->kind = it.kind == Item::GROUP ? 0 : it.kind == Item::SHAPE ? 1 : 2;
+    out->parent = it.parent;
+    out->shape_type = it.type;
+    out->material_id = it.material;
+    out->n_children = (uint32_t)it.children.size();
+    out->n_triangles = (uint32_t)(it.points.size() / 9);
+    out->closed = it.closed;
+    out->smooth = it.normals.empty() ? 0 : 1;
+    out->minimum = it.minimum, out->maximum = it.maximum;
+    it.transform.to16(out->transform);
+    return RTC_OK;
+}
+
+uint32_t rtc_scene_child_count(rtc_scene *scene, int32_t parent) {
+    if (!scene) return 0;
+    if (parent < 0) return (uint32_t)scene->s.top_level.size();
+    if ((size_t)parent >= scene->s.items.size()) return 0;
+    return (uint32_t)scene->s.items[parent].children.size();
+}
+
+int rtc_scene_get_child(rtc_scene *scene, int32_t parent, uint32_t k, uint32_t *out_item) {
+    CHECK_SCENE(scene)
+    const std::vector<int> *list = nullptr;
+    if (parent < 0)
+        list = &scene->s.top_level;
+    else if ((size_t)parent < scene->s.items.size())
+        list = &scene->s.items[parent].children;
+    if (!list || k >= list->size() || !out_item) {
+        set_error("child %u of item %d out of range", k, parent);
+        return RTC_ERR_INVALID;
+    }
+    *out_item = (uint32_t)(*list)[k];
+    return RTC_OK;
+}
+
+int rtc_scene_get_material(rtc_scene *scene, uint32_t id, rtc_material *out) {
+    CHECK_SCENE(scene)
+    if (!out || id >= scene->s.materials.size()) {
+        set_error("material %u out of range", id);
+        return RTC_ERR_INVALID;
+    }
+    *out = scene->s.materials[id];
+    return RTC_OK;
+}
+
+int rtc_scene_get_triangles(rtc_scene *scene, uint32_t item, uint32_t first, uint32_t n, double *points,
+                            double *normals) {
+    CHECK_SCENE(scene)
+    if (item >= scene->s.items.size() || scene->s.items[item].kind != Item::TRIANGLES) {
+        set_error("item %u is not a run of triangles", item);
+        return RTC_ERR_INVALID;
+    }
+    const Item &it = scene->s.items[item];
+    if ((size_t)first + n > it.points.size() / 9) {
+        set_error("triangle range out of bounds");
+        return RTC_ERR_INVALID;
+    }
+    if (points) std::memcpy(points, it.points.data() + (size_t)first * 9, sizeof(double) * 9 * n);
+    if (normals) {
+        if (it.normals.empty()) {
+            set_error("item %u holds flat triangles", item);
+            return RTC_ERR_INVALID;
+        }
+        std::memcpy(normals, it.normals.data() + (size_t)first * 9, sizeof(double) * 9 * n);
+    }
+    return RTC_OK;
+}
+
+int rtc_scene_get_light(rtc_scene *scene, uint32_t index, rtc_light_info *out) {
+    CHECK_SCENE(scene)
+    if (!out || index >= scene->s.lights.size()) {
+        set_error("light %u out of range", index);
+        return RTC_ERR_INVALID;
+    }
+    const DLight &l = scene->s.lights[index];
+    std::memset(out, 0, sizeof *out);
+    out->is_area = l.is_area, out->usteps = l.usteps, out->vsteps = l.vsteps;
+    for (int i = 0; i < 3; i++) {
+        out->position[i] = l.position[i], out->intensity[i] = l.intensity[i];
+        out->corner[i] = l.corner[i], out->uvec[i] = l.uvec[i], out->vvec[i] = l.vvec[i];
+    }
+    return RTC_OK;
+}
+
+int rtc_scene_get_camera(rtc_scene *scene, uint32_t *hsize, uint32_t *vsize, double *field_of_view, double view[16]) {
+    CHECK_SCENE(scene)
+    if (!scene->s.has_camera) {
+        set_error("scene has no camera");
+        return RTC_ERR_STATE;
+    }
+    if (hsize) *hsize = scene->s.hsize;
+    if (vsize) *vsize = scene->s.vsize;
+    if (field_of_view) *field_of_view = scene->s.fov;
+    if (view) scene->s.view.to16(view);
+    return RTC_OK;
+}
+
 }  // extern "C"
