@@ -40,7 +40,7 @@ namespace rtc {
 #define RTC_NODES_PER_STEP 4          // BVH nodes one step may descend through
 #define RTC_SHARDS 8u  // tile counters of the persistent grid
 #ifndef RTC_STAY_MIN
-#define RTC_STAY_MIN 32  // lanes inside a pass below which the wave leaves the traversal to serve idle lanes
+#define RTC_STAY_MIN 16  // waiting lanes (finished pass / free) at which a wave leaves the traversal loop to serve them
 #endif
 #ifndef RTC_REFILL_MIN
 #define RTC_REFILL_MIN 1  // free lanes needed before a wave assigns new pixels
@@ -841,13 +841,13 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         for (;;) {
             const unsigned long long act = __ballot(alive && in_pass);
             if (!act) break;
-            if (PERSISTENT && (unsigned)__popcll(act) < prm.stay_min) {
-                // few lanes are still inside a pass: leave if some lane could use the time (finished pass, or a
-                // free lane that can take a new pixel)
+            if (PERSISTENT) {
+                // leave the traversal once enough lanes wait to be served (pass finished -> state machine, or free
+                // and a pixel is available): the state machine then runs for a batch of lanes, not for each one
                 unsigned long long idle = __ballot(alive && !in_pass);
                 const unsigned long long dead = __ballot(!alive);
                 if (!(exhausted && r_next == r_end) && (unsigned)__popcll(dead) >= prm.refill_min) idle |= dead;
-                if (idle) break;
+                if ((unsigned)__popcll(idle) >= prm.stay_min) break;
             }
             if (alive && in_pass) {
 #define RTC_PUSH(v)                                                 \
@@ -901,8 +901,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         const DBvhNode &n = s.bvh[ref];
                         double tl, tr;
                         CNT(ST_BOX, 2);
-                        const bool hl = slab(n.lmin, n.lmax, inv_d, oi, lo, T.lim, tl);
-                        const bool hr = slab(n.rmin, n.rmax, inv_d, oi, lo, T.lim, tr);
+                        // containers pass: a subtree of paired primitives (spheres) matters only where its box
+                        // reaches the hit point -- a sphere wholly before the hit toggles in and out again
+                        const bool cont = T.mode == MODE_CONTAINER;
+                        const bool hl = slab(n.lmin, n.lmax, inv_d, oi, (cont && (n.flags & 1)) ? T.lim : lo, T.lim, tl);
+                        const bool hr = slab(n.rmin, n.rmax, inv_d, oi, (cont && (n.flags & 2)) ? T.lim : lo, T.lim, tr);
                         const int cl = n.left, cr = n.right;
                         if (hl && hr) {
                             const bool left_first = tl <= tr;

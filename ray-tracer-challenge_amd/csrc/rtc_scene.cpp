@@ -496,6 +496,21 @@ void Scene::build_bvh() {
     }
     bvh_max_depth = b.max_depth;
 
+    // "paired" subtrees hold only primitives whose records always come in pairs on both sides of their interior
+    // (spheres: two records or none, shape.rs:218-239).  Such a primitive can only be an open container at the
+    // hit if its records straddle the hit, so the containers pass may skip paired subtrees whose box ends
+    // before the hit point (rtc_kernels.hip, MODE_CONTAINER).
+    std::vector<uint8_t> paired(b.nodes.size(), 0);
+    for (int k = (int)b.nodes.size() - 1; k >= 0; k--) {  // children are created after their parent
+        const BuildNode &n = b.nodes[k];
+        if (n.left < 0) {
+            bool all = true;
+            for (int q = 0; q < n.count; q++) all = all && prims[order[n.first + q]].type == PT_SPHERE;
+            paired[k] = all;
+        } else {
+            paired[k] = paired[n.left] && paired[n.right];
+        }
+    }
     // Breadth-first relayout of the INTERNAL nodes only; every node stores both children's boxes.
     // Leaves become child references ~((first << 3) | (count - 1)), `first` relative to prim_list.
     const int32_t base = (int32_t)unbounded.size();
@@ -532,6 +547,7 @@ void Scene::build_bvh() {
             }
             d.left = (l.left >= 0) ? new_index[n.left] : leaf_ref(l);
             d.right = (r.left >= 0) ? new_index[n.right] : leaf_ref(r);
+            d.flags = (paired[n.left] ? 1 : 0) | (paired[n.right] ? 2 : 0);
             bvh[new_index[t]] = d;
         }
     }

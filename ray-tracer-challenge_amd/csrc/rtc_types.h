@@ -95,7 +95,8 @@ struct DBvhNode {
     float lmin[3], lmax[3];
     float rmin[3], rmax[3];
     int32_t left, right;
-    int32_t pad[2];
+    int32_t flags;  // bit 0 / 1: the left / right subtree holds "paired" primitives only (see Scene::build_bvh)
+    int32_t pad;
 };
 
 struct DCamera {
@@ -135,7 +136,7 @@ struct DRenderParams {
     uint32_t tiles_x, tiles_y;  // 8x8 pixel tiles covering hsize x local_rows
     uint32_t persistent;        // 1: persistent grid + lane refill, 0: one workgroup per tile
     uint32_t dyn_base;          // first tile handed out through the device-wide counters (= grid size)
-    uint32_t stay_min;          // lanes inside a pass below which a wave leaves the traversal loop (persistent)
+    uint32_t stay_min;          // waiting lanes at which a wave leaves the traversal loop to serve them (persistent)
     uint32_t refill_min;        // free lanes a wave waits for before it assigns new pixels (1..64)
 };
 
