@@ -339,6 +339,7 @@ struct orc_world {
     int nobjects, cap_objects;
     light_t *lights;
     int nlights, cap_lights;
+    int depth_override; /* 0: the reference's literal 5 (camera.rs:80); n > 0: bounce budget n - 1 */
     /* camera.rs:7-14 */
     int has_camera;
     uint32_t hsize, vsize;
@@ -413,6 +414,9 @@ static void xs_sort_from(xs_t *l, int from) {
     } while (0)
 
 orc_world *orc_world_new(void) { return (orc_world *)calloc(1, sizeof(orc_world)); }
+/* Test hook: the reference hard-codes the bounce budget 5 (camera.rs:80); the product exposes it as an option, so
+ * the oracle can be asked for other budgets too. */
+void orc_world_set_depth(orc_world *w, int depth) { w->depth_override = depth + 1; }
 
 void orc_world_free(orc_world *w) {
     if (!w) return;
@@ -1215,7 +1219,7 @@ static void *render_worker(void *arg) {
         for (uint32_t x = 0; x + 1 < w->hsize; x += j->col_step) {
             ray_t ray = camera_ray_for_pixel(w, x, y);
             j->counters.primary++;
-            v3 c = world_color_at(w, &ray, 5); /* camera.rs:80 */
+            v3 c = world_color_at(w, &ray, w->depth_override ? w->depth_override - 1 : 5); /* camera.rs:80 */
             double *px = j->out + ((size_t)y * w->hsize + x) * 3;
             px[0] = c.x, px[1] = c.y, px[2] = c.z;
         }

@@ -88,6 +88,7 @@ void orc_view_transform(const double from[3], const double to[3], const double u
 /* ---- world construction ---- */
 orc_world *orc_world_new(void);
 void orc_world_free(orc_world *w);
+void orc_world_set_depth(orc_world *w, int depth); /* test hook; default = the reference's 5 (camera.rs:80) */
 
 /* returns material index */
 int orc_add_material(orc_world *w, const orc_material *m);

@@ -296,8 +296,11 @@ class World:
         return self.L.orc_set_camera(self.h, hsize, vsize, fov, _d16(identity() if view is None else view))
 
     # hot path
-    def render(self, threads=None, subset=None):
+    def render(self, threads=None, subset=None, depth=None):
         threads = threads or min(os.cpu_count() or 1, 16)
+        self.L.orc_world_set_depth.argtypes = [C.c_void_p, C.c_int]
+        self.L.orc_world_set_depth.restype = None
+        self.L.orc_world_set_depth(self.h, 5 if depth is None else depth)
         out = np.zeros((self.vsize, self.hsize, 3), dtype=np.float64)
         st = Stats()
         if subset is None:

@@ -1,0 +1,165 @@
+"""GPU parity beyond the sample scenes: every feature of the path that the reference's own tests exercise but the
+YAML samples do not -- patterns (pattern.rs), area lights (light.rs:79-134), capped / truncated cylinders and cones
+(Q7, Q8, Q10), nested groups with per-level normal renormalisation (shape.rs:82-103), flat triangles, overlapping
+glass (n1/n2, intersection.rs:396-443), casts_shadow = false (Q5), several lights with secondary rays (Q3), bounce
+budgets 0..5, portrait cameras.  Each scene is rendered through the C ABI on the GPU and by the oracle."""
+import math
+
+import numpy as np
+import pytest
+
+import scene_feed as sf
+from scene_feed import rtc
+
+pytestmark = pytest.mark.gpu
+
+M = rtc.Matrix
+PI = math.pi
+
+
+def _cam(w=96, h=64, frm=(0, 2.5, -7), to=(0, 1, 0), fov=PI / 3):
+    return rtc.Camera(w, h, fov, rtc.compute_view_transformation(frm, to, (0, 1, 0)))
+
+
+def _check(world, cam, label, **opts):
+    scene = cam.compile(world, device=0)
+    try:
+        gpu = scene.render(**opts)
+        gpu2 = scene.render(schedule=2, **opts)  # the persistent schedule must agree bit for bit
+    finally:
+        scene.close()
+    ow = sf.to_oracle(world, cam)
+    ref = ow.render() if "depth" not in opts else ow.render(depth=opts["depth"])
+    rep = sf.compare(gpu, ref)
+    print(f"[parity] {label}: {rep}")
+    assert rep["nan"] == 0 and rep["max_8bit"] <= 1 and rep["max_abs"] < 1e-9, rep
+    assert np.array_equal(gpu, gpu2)
+    assert float(np.abs(gpu).sum()) > 0
+    return gpu
+
+
+def _floor(**kw):
+    return rtc.Plane(material=rtc.Material(**kw))
+
+
+LIGHT = [rtc.PointLight((-6, 8, -8), (1, 1, 1))]
+
+
+def test_every_pattern_kind():
+    P = rtc
+    stripes = P.StripePattern(P.SolidPattern((1, 0.2, 0.2)), P.SolidPattern((0.2, 0.2, 1)), M.scaling(0.25, 1, 1).rotate_y(0.4))
+    checker = P.CheckerPattern(P.SolidPattern((0.9, 0.9, 0.9)), stripes, M.scaling(0.7, 0.7, 0.7))
+    objs = [
+        rtc.Plane(material=rtc.Material(pattern=checker, reflectivity=0.2, specular=0.0)),
+        rtc.Sphere(M.translation(-2.6, 1, 0), rtc.Material(pattern=P.GradientPattern((1, 0, 0), (0, 0, 1), M.scaling(2, 1, 1).translate(-1, 0, 0)))),
+        rtc.Sphere(M.translation(0, 1, 0.5), rtc.Material(pattern=P.RingPattern((0.1, 0.8, 0.1), (1, 1, 0), M.scaling(0.2, 0.2, 0.2).rotate_x(1.0)))),
+        rtc.Cube(M.scaling(0.8, 0.8, 0.8).rotate_y(0.6).translate(2.6, 0.8, 0), rtc.Material(pattern=P.RadialGradientPattern((1, 1, 1), (0.1, 0.1, 0.6), M.scaling(0.3, 0.3, 0.3)))),
+        rtc.Cylinder(M.scaling(0.5, 1, 0.5).translate(-1.2, 0, -2.2), rtc.Material(pattern=P.BlendedPattern(P.StripePattern(transformation=M.scaling(0.3, 1, 1)), P.StripePattern(transformation=M.scaling(0.3, 1, 1).rotate_y(PI / 2)))), 0.0, 1.5, True),
+        rtc.Sphere(M.scaling(0.6, 0.6, 0.6).translate(1.3, 0.6, -2.3), rtc.Material(pattern=P.TestPattern(), ambient=0.4)),
+        rtc.Sphere(M.scaling(0.4, 0.4, 0.4).translate(0, 0.4, -3), rtc.Material(pattern=P.SolidPattern((0.3, 0.9, 0.9)))),
+    ]
+    _check(rtc.World(objs, LIGHT), _cam(), "patterns")
+
+
+def test_negative_coordinates_in_patterns():
+    # Rust's % is fmod: floor(-0.1) % 2 == -1 -> colour b, floor(-1.1) % 2 == -0 -> colour a (pattern.rs:152-162)
+    pat = rtc.CheckerPattern(rtc.SolidPattern((1, 1, 1)), rtc.SolidPattern((0, 0, 0)))
+    objs = [rtc.Plane(material=rtc.Material(pattern=pat, specular=0)),
+            rtc.Plane(M.rotation_x(PI / 2).translate(0, 0, 6), rtc.Material(pattern=rtc.StripePattern(), specular=0))]
+    _check(rtc.World(objs, LIGHT), _cam(frm=(0.3, 3, -6), to=(-0.4, 0, 0)), "negative pattern coordinates")
+
+
+def test_area_light_soft_shadows():
+    lights = [rtc.AreaLight((-1, 4, -5), (2, 0, 0), 3, (0, 2, 0), 2, (1.2, 1.1, 1.0)), rtc.PointLight((6, 6, -6), (0.3, 0.3, 0.4))]
+    objs = [_floor(color=(1, 0.9, 0.9), specular=0), rtc.Sphere(M.translation(0, 1, 0), rtc.Material(color=(0.3, 0.6, 1), reflectivity=0.3)),
+            rtc.Cube(M.scaling(0.5, 0.5, 0.5).translate(1.8, 0.5, -1), rtc.Material(color=(1, 0.5, 0.2)))]
+    _check(rtc.World(objs, lights), _cam(), "area light")
+
+
+def test_cylinders_and_cones_with_and_without_caps():
+    objs = [_floor(color=(0.8, 0.8, 0.8), reflectivity=0.1)]
+    x = -3.0
+    for closed in (False, True):
+        for ctor, lo, hi in ((rtc.Cylinder, 0.0, 1.5), (rtc.Cylinder, -0.5, 0.7), (rtc.Cone, -1.0, 0.0), (rtc.Cone, -0.8, 0.6), (rtc.Cone, 0.2, 1.0)):
+            t = M.rotation_z(0.3 * x).rotate_x(0.2).scale(0.45, 0.9, 0.45).translate(x, 1.0, 0.4 * math.sin(x))
+            objs.append(ctor(t, rtc.Material(color=(0.5 + 0.1 * x, 0.6, 0.5 - 0.1 * x), reflectivity=0.15), lo, hi, closed))
+            x += 0.65
+    objs.append(rtc.Cylinder(M.scaling(0.2, 1, 0.2).translate(0, 0, 3), rtc.Material(color=(1, 1, 0))))  # infinite
+    objs.append(rtc.Cone(M.scaling(0.3, 0.6, 0.3).translate(2.5, 1.5, 3), rtc.Material(color=(0, 1, 1))))  # infinite, open
+    _check(rtc.World(objs, LIGHT), _cam(128, 72, (0, 3, -8)), "cylinders and cones")
+
+
+def _hexagon():
+    # ray_tracer/examples/hexagon.rs:8-66: six sides, each a group of a corner sphere and an edge cylinder
+    hexa = rtc.Group()
+    for n in range(6):
+        side = rtc.Group(transformation=M.rotation_y(n * PI / 3))
+        side.add_child(rtc.Sphere(M.scaling(0.25, 0.25, 0.25).translate(0, 0, -1)))
+        side.add_child(rtc.Cylinder(M.scaling(0.25, 1, 0.25).rotate_z(-PI / 2).rotate_y(-PI / 6).translate(0, 0, -1), None, 0.0, 1.0, False))
+        hexa.add_child(side)
+    return hexa
+
+
+def test_nested_groups_of_analytic_shapes():
+    hexa = _hexagon()
+    hexa.transformation = M.rotation_x(-0.5).scale(1.5, 1.2, 1.5).translate(0, 1.2, 0)
+    outer = rtc.Group(transformation=M.rotation_z(0.2).translate(0.3, 0, 0), children=[hexa, rtc.Cube(M.scaling(0.3, 0.3, 0.3).translate(0, 1.2, 0), rtc.Material(color=(1, 0.3, 0.3), reflectivity=0.4))])
+    objs = [_floor(color=(0.7, 0.8, 0.7), reflectivity=0.2), outer]
+    _check(rtc.World(objs, LIGHT), _cam(), "nested groups")
+
+
+def test_flat_and_smooth_triangles_outside_and_inside_groups():
+    tri = rtc.Triangle((0, 2, 0), (-1.5, 0.2, 0.3), (1.5, 0.2, -0.3), material=rtc.Material(color=(1, 0.8, 0.2), reflectivity=0.3))
+    smooth = rtc.SmoothTriangle((2.5, 2, 1), (1.2, 0.1, 1), (3.6, 0.1, 1.2), (0, 1, -0.3), (-0.6, 0.2, -1), (0.6, 0.2, -1))
+    g = rtc.Group(transformation=M.rotation_y(0.7).translate(-2.5, 0, 1), material=rtc.Material(color=(0.2, 0.9, 0.4)))
+    g.add_child(rtc.Triangle((0, 1.8, 0), (-1, 0, 0), (1, 0, 0)))
+    g.add_child(rtc.SmoothTriangle((0, 1.8, 0.5), (-1, 0, 0.5), (1, 0, 0.5), (0, 1, -1), (-1, 0, -1), (1, 0, -1)))
+    objs = [_floor(color=(0.9, 0.9, 1.0)), tri, smooth, g]
+    _check(rtc.World(objs, LIGHT), _cam(), "triangles")
+
+
+def test_overlapping_glass_containers():
+    # intersection.rs:396-443: A (n 1.5) contains B (2.0) and C (2.5) which overlap each other
+    a = rtc.Sphere(M.scaling(2, 2, 2).translate(0, 2, 0), rtc.Material(transparency=0.9, reflectivity=0.3, refractive_index=1.5, diffuse=0.1, color=(1, 0.9, 0.9)))
+    b = rtc.Sphere(M.translation(-0.45, 2, -0.25), rtc.Material(transparency=0.8, reflectivity=0.2, refractive_index=2.0, diffuse=0.2, color=(0.9, 1, 0.9)))
+    c = rtc.Sphere(M.translation(0.45, 2, 0.25), rtc.Material(transparency=0.7, reflectivity=0.5, refractive_index=2.5, diffuse=0.2, color=(0.9, 0.9, 1)))
+    wall = rtc.Plane(M.rotation_x(PI / 2).translate(0, 0, 6), rtc.Material(pattern=rtc.CheckerPattern(rtc.SolidPattern((0.9, 0.2, 0.2)), rtc.SolidPattern((1, 1, 1))), specular=0))
+    pool = rtc.Cube(M.scaling(3, 0.4, 3).translate(0, -0.2, 0), rtc.Material(transparency=0.6, refractive_index=1.33, reflectivity=0.4, color=(0.2, 0.4, 0.8), diffuse=0.3))
+    objs = [_floor(pattern=rtc.CheckerPattern(), specular=0), wall, a, b, c, pool]
+    _check(rtc.World(objs, LIGHT), _cam(112, 72, (0, 3, -8), (0, 1.5, 0)), "overlapping glass")
+
+
+def test_casts_shadow_false_and_nearest_hit_rule():
+    # world.rs:86-87 (Q5): only the NEAREST positive hit decides; a non-casting object in front of a casting one
+    # lets the light through
+    ghost = rtc.Sphere(M.translation(0, 3, -1.2), rtc.Material(color=(1, 0.2, 0.2), casts_shadow=False))
+    solid = rtc.Sphere(M.scaling(0.7, 0.7, 0.7).translate(-1.0, 1.6, 0.4), rtc.Material(color=(0.2, 0.2, 1)))
+    glass = rtc.Sphere(M.translation(1.6, 1, 0), rtc.Material(transparency=0.9, refractive_index=1.5, casts_shadow=False, diffuse=0.1, reflectivity=0.9))
+    objs = [_floor(color=(1, 1, 1), specular=0), ghost, solid, glass]
+    _check(rtc.World(objs, [rtc.PointLight((0.5, 9, -3), (1, 1, 1))]), _cam(), "casts_shadow")
+
+
+def test_three_lights_multiply_secondary_rays():
+    # world.rs:45-68 (Q3): reflected + refracted colour is added once per light
+    lights = [rtc.PointLight((-6, 8, -8), (0.5, 0.5, 0.5)), rtc.PointLight((6, 8, -8), (0.4, 0.3, 0.3)), rtc.PointLight((0, 9, 4), (0.2, 0.3, 0.4))]
+    objs = [_floor(color=(0.9, 0.9, 0.9), reflectivity=0.5), rtc.Sphere(M.translation(-1.2, 1, 0), rtc.Material(color=(1, 0.3, 0.3), reflectivity=0.6)),
+            rtc.Sphere(M.translation(1.2, 1, 0), rtc.Material(transparency=0.9, reflectivity=0.9, refractive_index=1.5, diffuse=0.1, color=(0.8, 1, 0.8)))]
+    _check(rtc.World(objs, lights), _cam(), "three lights")
+
+
+@pytest.mark.parametrize("depth", [0, 1, 3])
+def test_bounce_budget(depth):
+    world, cam = sf.load("reflective_world", 96, 48)
+    _check(world, cam, f"depth {depth}", depth=depth)
+
+
+def test_portrait_camera_and_no_lights():
+    # camera.rs:25-33: aspect < 1; world.rs:42-76 with no lights: everything is black
+    objs = [_floor(color=(0.9, 0.9, 0.9), reflectivity=0.3), rtc.Sphere(M.translation(0, 1, 0), rtc.Material(color=(0.2, 1, 0.4)))]
+    _check(rtc.World(objs, LIGHT), _cam(40, 90), "portrait")
+    scene = _cam(24, 16).compile(rtc.World(objs, []), device=0)
+    try:
+        img = scene.render()
+    finally:
+        scene.close()
+    assert np.all(img == 0.0)
