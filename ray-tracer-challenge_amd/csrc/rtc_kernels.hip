@@ -436,6 +436,11 @@ DEV V3 pattern_at_shape(const DScene &s, int pat, const DPrim &p, V3 world_point
     return pattern_eval(s, pat, pp);
 }
 
+// f64::powf (material.rs:67).  Kept out of line on purpose: inlined, the compiler hoists pow's ~13 f64 constants out of
+// the ray loop, runs out of registers and parks them in scratch memory at the start of EVERY wave -- 6.6 KB per wave,
+// 0.65 GB of write-back per 4K frame of 129 600 short-lived waves (profiles/r1_v5_teapot4k.txt, WRITE_SIZE).
+__device__ __attribute__((noinline)) double specular_pow(double base, double exponent) { return pow(base, exponent); }
+
 // Material::lighting, material.rs:20-75
 DEV V3 lighting(const DMaterial &m, V3 color, V3 light_pos, V3 light_int, V3 point, V3 eye, V3 normal,
                 double intensity) {
@@ -451,7 +456,7 @@ DEV V3 lighting(const DMaterial &m, V3 color, V3 light_pos, V3 light_int, V3 poi
         if (rde <= 0.) {
             specular = mk(0., 0., 0.) * intensity;
         } else {
-            const double factor = pow(rde, m.shininess);
+            const double factor = specular_pow(rde, m.shininess);
             specular = light_int * m.specular * factor * intensity;
         }
     }
