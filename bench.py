@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="stress_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 rehearsal on a one-GPU box: every rank renders on cuda:0 and the gather runs over gloo "
+                         "through host memory (RCCL refuses two ranks on one device); numbers are not comparable")
     ap.add_argument("--cpu-sample-stride", type=int, default=0, help="0 = choose for ~10-20 s of CPU work")
     ap.add_argument("--use-bvh", type=int, default=0, help="0 auto, 1 force BVH, 2 force brute force (A/B only)")
     ap.add_argument("--schedule", type=int, default=0, help="0 auto, 1 workgroup per tile, 2 persistent (A/B only)")
@@ -68,8 +71,13 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert world_size == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world_size}"
     else:
         torch.cuda.set_device(local_rank)
@@ -112,12 +120,23 @@ def main():
             idx[r, : len(m)] = m
         index = torch.from_numpy(idx.reshape(-1)).to(dev)
 
+    def exchange():
+        """the one exchange step of the path: every rank's row tiles -> rank 0 -> canvas (camera.rs:87-91)"""
+        if args.rehearse_on_one_gpu:
+            host = buf.cpu()
+            parts = [torch.empty_like(host) for _ in range(world_size)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            if rank == 0:
+                canvas_ext.index_copy_(0, index, torch.cat(parts, dim=0).to(dev))
+            return
+        dist.gather(buf, gather_list, dst=0)
+        if rank == 0:
+            canvas_ext.index_copy_(0, index, torch.cat(gather_list, dim=0))
+
     def step():
         scene.render_device(buf.data_ptr(), stream.cuda_stream, **ropts)
         if distributed:
-            dist.gather(buf, gather_list, dst=0)
-            if rank == 0:
-                canvas_ext.index_copy_(0, index, torch.cat(gather_list, dim=0))
+            exchange()
 
     def sync_all():
         if distributed:
@@ -152,9 +171,7 @@ def main():
         scene.render_device(buf.data_ptr(), stream.cuda_stream, **ropts)
         ev[i][1].record(stream)
         if distributed:
-            dist.gather(buf, gather_list, dst=0)
-            if rank == 0:
-                canvas_ext.index_copy_(0, index, torch.cat(gather_list, dim=0))
+            exchange()
     sync_all()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
@@ -165,6 +182,14 @@ def main():
     else:
         kernel_ms_max = kernel_ms
 
+    if distributed and args.rehearse_on_one_gpu and rank == 0:
+        # the assembled canvas must equal a one-rank render of the whole frame, bit for bit
+        full = torch.zeros((vsize, hsize, 3), dtype=torch.float64, device=dev)
+        kw = {k: v for k, v in ropts.items() if not k.startswith("tile_")}
+        scene.render_device(full.data_ptr(), stream.cuda_stream, **kw)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(full, canvas_ext[:vsize]), "gathered canvas differs from the single-rank frame"
+        print("[rehearsal] gathered canvas == single-rank frame", file=sys.stderr)
     if rank != 0:
         if distributed:
             dist.barrier()
