@@ -442,10 +442,10 @@ DEV V3 pattern_at_shape(const DScene &s, int pat, const DPrim &p, V3 world_point
 __device__ __attribute__((noinline)) double specular_pow(double base, double exponent) { return pow(base, exponent); }
 
 // Material::lighting, material.rs:20-75
-DEV V3 lighting(const DMaterial &m, V3 color, V3 light_pos, V3 light_int, V3 point, V3 eye, V3 normal,
-                double intensity) {
+// `lightv` = normalize(light.position - point) (material.rs:37): for a point light that is, bit for bit, the
+// direction of the shadow ray just traced (world.rs:79-83), so the caller passes it instead of normalising again.
+DEV V3 lighting(const DMaterial &m, V3 color, V3 lightv, V3 light_int, V3 eye, V3 normal, double intensity) {
     const V3 effective = cmul(color, light_int);
-    const V3 lightv = normalize(light_pos - point);
     const V3 ambient = effective * m.ambient;
     const double ldn = dot(lightv, normal);
     V3 diffuse = mk(0., 0., 0.), specular = mk(0., 0., 0.);
@@ -705,36 +705,36 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
 
     // binds this lane to pixel `pix`: primary ray and a fresh path state, or a black pixel (Q1 / tile padding)
     auto init_pixel = [&]() {
-            const unsigned tile = pix >> 6, q = pix & 63u;
-            const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
-            const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
-            const unsigned y = canvas_row(prm, l);
-            if (x < s.cam.hsize && l < prm.local_rows) {
-                // camera.rs:72,78: rows 0..vsize-1 and columns 0..hsize-1 (exclusive) -- Q1
-                if ((x + 1u < s.cam.hsize) && (y + 1u < s.cam.vsize)) {
-                    // Camera::ray_for_pixel, camera.rs:41-59
-                    const double xo = ((double)x + 0.5) * s.cam.pixel_size;
-                    const double yo = ((double)y + 0.5) * s.cam.pixel_size;
-                    const double wx = s.cam.half_width - xo;
-                    const double wy = s.cam.half_height - yo;
-                    const V3 pixel = xf_point(s.cam.inv, mk(wx, wy, -1.));
-                    ray.o = xf_point(s.cam.inv, mk(0., 0., 0.));
-                    ray.d = normalize(pixel - ray.o);
-                    park3(pk, PK_COLOR, mk(0., 0., 0.));
-                    pk[PK_W * RTC_WAVE] = 1.;
-                    mult = 1.;
-                    remaining = (int)prm.depth;
-                    sp = 0;
-                    rays = 1;
-                    T.mode = MODE_CLOSEST;
-                    T.lim = inf, T.prim = -1;
-                    CNT(ST_PRIMARY, 1);
-                    alive = true;
-                } else {
-                    double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
-                    px[0] = 0., px[1] = 0., px[2] = 0.;  // Canvas::new: black
-                }
+        const unsigned tile = pix >> 6, q = pix & 63u;
+        const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
+        const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
+        const unsigned y = canvas_row(prm, l);
+        if (x < s.cam.hsize && l < prm.local_rows) {
+            // camera.rs:72,78: rows 0..vsize-1 and columns 0..hsize-1 (exclusive) -- Q1
+            if ((x + 1u < s.cam.hsize) && (y + 1u < s.cam.vsize)) {
+                // Camera::ray_for_pixel, camera.rs:41-59
+                const double xo = ((double)x + 0.5) * s.cam.pixel_size;
+                const double yo = ((double)y + 0.5) * s.cam.pixel_size;
+                const double wx = s.cam.half_width - xo;
+                const double wy = s.cam.half_height - yo;
+                const V3 pixel = xf_point(s.cam.inv, mk(wx, wy, -1.));
+                ray.o = xf_point(s.cam.inv, mk(0., 0., 0.));
+                ray.d = normalize(pixel - ray.o);
+                park3(pk, PK_COLOR, mk(0., 0., 0.));
+                pk[PK_W * RTC_WAVE] = 1.;
+                mult = 1.;
+                remaining = (int)prm.depth;
+                sp = 0;
+                rays = 1;
+                T.mode = MODE_CLOSEST;
+                T.lim = inf, T.prim = -1;
+                CNT(ST_PRIMARY, 1);
+                alive = true;
+            } else {
+                double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
+                px[0] = 0., px[1] = 0., px[2] = 0.;  // Canvas::new: black
             }
+        }
     };
     // the pixel is finished: Canvas::write_pixel (camera.rs:87-91)
     auto write_pixel = [&]() {
@@ -1023,8 +1023,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 const V3 over = ray.o;  // the shadow ray starts at over_point (world.rs:50, 79)
                 V3 col = ld3(m.color);
                 if (PATTERNS && m.pattern >= 0) col = pattern_at_shape(s, m.pattern, p, over);
-                const V3 c = lighting(m, col, ld3(lt.position), ld3(lt.intensity), over, unpark3(pk, PK_EYE),
-                                      unpark3(pk, PK_NORMAL), inten);
+                const V3 lightv = lt.is_area ? normalize(ld3(lt.position) - over) : ray.d;
+                const V3 c = lighting(m, col, lightv, ld3(lt.intensity), unpark3(pk, PK_EYE), unpark3(pk, PK_NORMAL), inten);
                 CNT(ST_LIGHT, 1);
                 park3(pk, PK_SURFACE, (li == 0) ? c : unpark3(pk, PK_SURFACE) + c);  // world.rs:70 left fold
                 li++;

@@ -512,7 +512,7 @@ void Scene::build_bvh() {
         }
     }
     // Breadth-first relayout of the INTERNAL nodes only; every node stores both children's boxes.
-    // Leaves become child references ~((first << 3) | (count - 1)), `first` relative to prim_list.
+    // Leaves become child references ~((first << 3) | (count - 1)), `first` relative to the leaf-record list (unbounded primitives first).
     const int32_t base = (int32_t)unbounded.size();
     auto leaf_ref = [&](const BuildNode &n) -> int32_t {
         bvh_max_leaf = std::max<uint32_t>(bvh_max_leaf, (uint32_t)n.count);
@@ -616,10 +616,6 @@ int Scene::upload(int dev) {
     {
         std::vector<int32_t> list(unbounded);
         list.insert(list.end(), bvh_prims.begin(), bvh_prims.end());
-        if ((rc = upload_vec(*this, list, dscene.prim_list))) return rc;
-        std::vector<int32_t> all(prims.size());
-        for (size_t i = 0; i < all.size(); i++) all[i] = (int32_t)i;
-        if ((rc = upload_vec(*this, all, dscene.all_list))) return rc;
         // intersection-loop records, once in list order and once in primitive order
         auto make_leaf = [&](int32_t pi) {
             const DPrim &p = prims[pi];

@@ -8,7 +8,8 @@
 //   DMaterial[] 88 B, DLight[] 136 B, DPattern[] 160 B
 //   DBvhNode[]  64 B internal nodes of the binary BVH over the bounded primitives (breadth-first order),
 //               each holding BOTH children's boxes in outward-rounded f32
-//   int prim_list[] unbounded primitives (tested for every ray) followed by the BVH leaves' primitive runs
+//   DLeaf[]     intersection-loop records: unbounded primitives (tested for every ray) followed by the BVH
+//               leaves' primitive runs; a second copy in primitive order serves brute-force mode
 #pragma once
 #include <stdint.h>
 
@@ -90,7 +91,7 @@ struct DPattern {
 // rays pay one L1 tag look-up per lane per load, which is what bounds the traversal, so the boxes are stored
 // in f32, rounded OUTWARD (they are culling volumes of this build, not reference arithmetic; the slab test
 // itself runs in f64).  Child references: >= 0 is the index of another internal node; < 0 encodes a leaf as
-// ~((first << 3) | (count - 1)) with `first` an offset into DScene::prim_list / DScene::leaves.
+// ~((first << 3) | (count - 1)) with `first` an offset into DScene::leaves.
 struct DBvhNode {
     float lmin[3], lmax[3];
     float rmin[3], rmax[3];
@@ -116,9 +117,7 @@ struct DScene {
     const DLight *lights;
     const DPattern *patterns;
     const DBvhNode *bvh;
-    const int32_t *prim_list;  // [0, n_unbounded): primitives tested for every ray; then the BVH leaves' runs
-    const int32_t *all_list;   // identity 0..n_prims-1 (brute-force mode)
-    const DLeaf *leaves;       // DLeaf records in prim_list order
+    const DLeaf *leaves;       // [0, n_unbounded): primitives tested for every ray; then the BVH leaves' runs
     const DLeaf *leaves_all;   // DLeaf records in primitive order (brute-force mode)
     double root_min[3], root_max[3];
     int32_t root_ref;          // child reference of the BVH root (valid when n_bounded > 0)
