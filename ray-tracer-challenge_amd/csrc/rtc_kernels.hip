@@ -570,6 +570,7 @@ DEV V3 unpark3(const lds_f64 *base, int slot) {
 template <bool GROUPS>
 DEV V3 normal_at(const DScene &s, const DPrim &p, V3 world_point, double u, double v) {
     V3 n;
+    if (p.type == PT_PLANE) return ld3(p.plane_normal);  // constant per plane: evaluated at commit (rtc_scene.cpp)
     if (p.type >= PT_TRIANGLE) {
         const DTri &tr = s.tris[p.tri];
         if (p.type == PT_TRIANGLE)
@@ -585,7 +586,6 @@ DEV V3 normal_at(const DScene &s, const DPrim &p, V3 world_point, double u, doub
         if (GROUPS)
             for (int k = 0; k < p.chain_len - 1; k++) lp = xf_point(s.xforms[s.chains[p.chain_off + k]].inv, lp);
         switch (p.type) {
-        case PT_PLANE: n = mk(0., 1., 0.); break;  // shape.rs:550-553 (the local point is not read)
         case PT_SPHERE:                            // shape.rs:273-279
             lp = xf_point(own, lp);
             n = lp - mk(0., 0., 0.);

@@ -257,6 +257,18 @@ int Scene::flatten() {
             p.tri = -1;
             p.own_xform = xi;
             p.chain_id = next_chain_id++;
+            if (it.type == RTC_PLANE) {
+                // normal_to_world up the chain, one normalisation per level (shape.rs:94-103); transpose(inverse) * n
+                // with the row-times-vector order of matrix.rs:348-365
+                Vec3 n = {0., 1., 0.};
+                for (int k = p.chain_len - 1; k >= 0; k--) {
+                    const double *m = xforms[chains[p.chain_off + k]].inv;
+                    const Vec3 r = {m[0] * n.x + m[4] * n.y + m[8] * n.z, m[1] * n.x + m[5] * n.y + m[9] * n.z,
+                                    m[2] * n.x + m[6] * n.y + m[10] * n.z};
+                    n = vnorm(r);
+                }
+                p.plane_normal[0] = n.x, p.plane_normal[1] = n.y, p.plane_normal[2] = n.z;
+            }
             Bounds lb, wb;
             bounds_empty(wb);
             const bool bounded = local_bounds(it, lb);

@@ -3,7 +3,7 @@
 // Data layout in HBM (all tables are immutable after rtc_scene_commit, one copy per GPU):
 //   DXform[]    rows 0..2 of a cofactor inverse (96 B each); one per Group / analytic shape
 //   int chains[] root-first lists of DXform indices (a primitive's parent chain + its own transform)
-//   DPrim[]     one per leaf shape in depth-first (== reference traversal) order, 56 B
+//   DPrim[]     one per leaf shape in depth-first (== reference traversal) order, 72 B
 //   DTri[]      triangle payloads (p1, e1, e2, n1..n3), 144 B
 //   DMaterial[] 88 B, DLight[] 136 B, DPattern[] 160 B
 //   DBvhNode[]  64 B internal nodes of the binary BVH over the bounded primitives (breadth-first order),
@@ -39,6 +39,9 @@ struct DPrim {
     int32_t tri;        // index into DTri[] or -1
     int32_t own_xform;  // DXform index of the shape's OWN transform (pattern lookup, Q13) or -1 (triangles)
     int32_t chain_id;   // primitives with equal chain_id share the same chain (lane-local ray cache key)
+    // PT_PLANE only: Shape::normal_at of a plane does not depend on the point (shape.rs:550-553), so the whole
+    // normal_to_world chain (shape.rs:94-103) is evaluated once on the host with the same operations
+    double plane_normal[3];
 };
 
 // Intersection-loop record (144 B), one per primitive and per list position: everything a ray/primitive test
