@@ -455,6 +455,11 @@ DEV V3 lighting(const DMaterial &m, V3 color, V3 lightv, V3 light_int, V3 eye, V
         const double rde = dot(rv, eye);
         if (rde <= 0.) {
             specular = mk(0., 0., 0.) * intensity;
+        } else if (rde < m.spec_skip_rde && fabs(light_int.x * m.specular * intensity) <= 1024. * fabs(ambient.x) &&
+                   fabs(light_int.y * m.specular * intensity) <= 1024. * fabs(ambient.y) &&
+                   fabs(light_int.z * m.specular * intensity) <= 1024. * fabs(ambient.z)) {
+            // far from the highlight: rde^shininess < 2^-66, so |specular| < 2^-56 |ambient| in every channel and
+            // `ambient + specular` rounds to `ambient` -- the result below is bit-identical without the pow
         } else {
             const double factor = specular_pow(rde, m.shininess);
             specular = light_int * m.specular * factor * intensity;

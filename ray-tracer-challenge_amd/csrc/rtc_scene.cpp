@@ -160,6 +160,7 @@ int Scene::flatten() {
         d.reflectivity = m.reflectivity, d.transparency = m.transparency, d.refractive_index = m.refractive_index;
         d.casts_shadow = m.casts_shadow ? 1 : 0;
         d.pattern = m.pattern;
+        d.spec_skip_rde = (std::isfinite(m.shininess) && m.shininess >= 1.0) ? std::exp2(-66.0 / m.shininess) : 0.0;
         if (m.pattern >= (int32_t)patterns.size()) {
             set_error("material references pattern %d, only %zu defined", m.pattern, patterns.size());
             return RTC_ERR_INVALID;

@@ -5,7 +5,7 @@
 //   int chains[] root-first lists of DXform indices (a primitive's parent chain + its own transform)
 //   DPrim[]     one per leaf shape in depth-first (== reference traversal) order, 72 B
 //   DTri[]      triangle payloads (p1, e1, e2, n1..n3), 144 B
-//   DMaterial[] 88 B, DLight[] 136 B, DPattern[] 160 B
+//   DMaterial[] 96 B, DLight[] 136 B, DPattern[] 160 B
 //   DBvhNode[]  64 B internal nodes of the binary BVH over the bounded primitives (breadth-first order),
 //               each holding BOTH children's boxes in outward-rounded f32
 //   DLeaf[]     intersection-loop records: unbounded primitives (tested for every ray) followed by the BVH
@@ -72,6 +72,9 @@ struct DMaterial {
     double reflectivity, transparency, refractive_index;
     int32_t casts_shadow;
     int32_t pattern;
+    // reflect.dot(eye) below which pow(rde, shininess) < 2^-66: the specular term is then too small to change
+    // `ambient + specular` in f64 and need not be evaluated (see lighting()); 0 = never skip
+    double spec_skip_rde;
 };
 
 struct DLight {
