@@ -95,6 +95,8 @@ typedef struct rtc_stats {
     uint64_t schlick_evals;
     uint64_t refract_evals;
     uint64_t overflow;        /* lanes that hit the iteration cap (0 in a valid render) */
+    uint64_t diag[10];        /* counting kernel only: shader cycles per stage summed over waves {refill, start, traverse,
+                                 shade}, then {rounds, lanes} of start / traverse / shade */
     double kernel_ms;         /* HIP-event time of the render kernel on its stream (rtc_render only) */
     double algorithmic_flops; /* SURVEY.md 8(d) flop table x the counters above */
 } rtc_stats;

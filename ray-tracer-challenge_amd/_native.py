@@ -72,6 +72,7 @@ class Stats(C.Structure):
         ("schlick_evals", C.c_uint64),
         ("refract_evals", C.c_uint64),
         ("overflow", C.c_uint64),
+        ("diag", C.c_uint64 * 10),
         ("kernel_ms", C.c_double),
         ("algorithmic_flops", C.c_double),
     ]

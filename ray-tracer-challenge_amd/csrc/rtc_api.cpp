@@ -293,6 +293,7 @@ static void fill_stats(Scene &s, const std::vector<uint64_t> &c, rtc_stats &st) 
     st.schlick_evals = c[ST_SCHLICK];
     st.refract_evals = c[ST_REFRACT];
     st.overflow = c[ST_OVERFLOW];
+    for (int i = 0; i < 10; i++) st.diag[i] = c[ST_CYC_REFILL + i];
     // SURVEY.md 8(d) flop table (+,-,*,/,sqrt,pow = 1 each)
     double cyl = 26, cone = 32;
     {

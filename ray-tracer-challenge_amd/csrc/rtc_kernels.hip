@@ -758,6 +758,20 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         rendered = alive;
     }
 
+    // STATS only: stage timing.  WCNT adds a wave-level quantity once (lane 0 carries it).
+#define WCNT(idx, n)                                                    \
+    do {                                                                \
+        if (STATS && lane == 0) cnt.c[idx] += (unsigned long long)(n);  \
+    } while (0)
+    unsigned long long stamp = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+#define STAGE_END(idx)                                                   \
+    do {                                                                 \
+        if (STATS) {                                                     \
+            const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+            WCNT(idx, now__ - stamp);                                    \
+            stamp = now__;                                               \
+        }                                                                \
+    } while (0)
     for (;;) {
         // =====================================================================================
         // refill: free lanes take the next pixels (wave-uniform control flow)
@@ -805,6 +819,14 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             }
             if (__ballot(alive) == 0ull) break;  // no pixel in flight and none left: the wave is done
         }
+        STAGE_END(ST_CYC_REFILL);
+        if (STATS) {
+            const unsigned long long m = __ballot(alive && !in_pass);
+            if (m) {
+                WCNT(ST_ROUNDS_START, 1);
+                WCNT(ST_LANES_START, __popcll(m));
+            }
+        }
         // =====================================================================================
         // World::intersect (world.rs:176-186) without materialising the list.
         // (A) lanes holding a fresh ray start its pass; (B) the BVH traversal advances in steps for every lane
@@ -847,10 +869,13 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 }
             }
         }
+        STAGE_END(ST_CYC_START);
         // ---- (B) traversal steps ----
         for (;;) {
             const unsigned long long act = __ballot(alive && in_pass);
             if (!act) break;
+            WCNT(ST_ROUNDS_TRAVERSE, 1);
+            WCNT(ST_LANES_TRAVERSE, __popcll(act));
             if (PERSISTENT) {
                 // leave the traversal once enough lanes wait to be served (pass finished -> state machine, or free
                 // and a pixel is available): the state machine then runs for a batch of lanes, not for each one
@@ -944,6 +969,14 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 }
 #undef RTC_PUSH
 #undef RTC_POP
+            }
+        }
+        STAGE_END(ST_CYC_TRAVERSE);
+        if (STATS) {
+            const unsigned long long m = __ballot(alive && !in_pass);
+            if (m) {
+                WCNT(ST_ROUNDS_SHADE, 1);
+                WCNT(ST_LANES_SHADE, __popcll(m));
             }
         }
         if (alive && !in_pass) {
@@ -1143,6 +1176,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         }
         if (PERSISTENT && !alive) write_pixel();  // the lane is free for the next pixel
         }  // if (alive)
+        STAGE_END(ST_CYC_SHADE);
     }
     if (!PERSISTENT && rendered) write_pixel();  // the whole tile at once
 

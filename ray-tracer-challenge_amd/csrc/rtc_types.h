@@ -160,6 +160,15 @@ enum StatIdx {
     ST_SCHLICK,
     ST_REFRACT,
     ST_OVERFLOW,
+    // diagnostics of the counting kernel: shader cycles (s_memtime) a wave spent per stage, summed over waves, and
+    // how many lanes took part -- where the time of a divergent workload goes
+    ST_CYC_REFILL,
+    ST_CYC_START,     // (A) lockstep list + traversal set-up
+    ST_CYC_TRAVERSE,  // (B)
+    ST_CYC_SHADE,     // (C) state machine
+    ST_ROUNDS_START, ST_LANES_START,
+    ST_ROUNDS_TRAVERSE, ST_LANES_TRAVERSE,  // one round = one look at the wave (RTC_STEPS_PER_CHECK steps)
+    ST_ROUNDS_SHADE, ST_LANES_SHADE,
     ST_COUNT
 };
 

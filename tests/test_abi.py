@@ -39,7 +39,7 @@ def test_struct_layouts_match_the_header():
     N = rtc._native
     assert ctypes.sizeof(N.Material) == 3 * 8 + 7 * 8 + 2 * 4
     assert ctypes.sizeof(N.RenderOpts) == 8 * 4
-    assert ctypes.sizeof(N.Stats) == 8 * (7 + 7 + 6) + 2 * 8
+    assert ctypes.sizeof(N.Stats) == 8 * (7 + 7 + 6 + 10) + 2 * 8
     assert ctypes.sizeof(N.SceneInfo) == 14 * 4 + 8
     o = N.RenderOpts()
     N.lib().rtc_render_opts_default(ctypes.byref(o))

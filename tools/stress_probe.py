@@ -14,3 +14,9 @@ for mode in sys.argv[4:]:
     else:
         t = time.time(); img = sc.render(collect_stats=("stats" in sys.argv))
         print("full", "%.2fs" % (time.time() - t), "kernel_ms", sc.last_stats["kernel_ms"], {k: sc.last_stats.get(k) for k in ("primary_rays", "shadow_rays", "secondary_rays", "container_passes", "overflow", "box_tests", "prim_tests")}, flush=True)
+        d = sc.last_stats.get("diag")
+        if d and sum(d):
+            tot = float(sum(d[:4])) or 1.0
+            print("  stage cycles (share): refill %.3f start %.3f traverse %.3f shade %.3f" % tuple(x / tot for x in d[:4]))
+            for name, r, l in (("start", d[4], d[5]), ("traverse", d[6], d[7]), ("shade", d[8], d[9])):
+                print("  %-9s rounds %d  lanes/round %.1f" % (name, r, l / max(r, 1)))
