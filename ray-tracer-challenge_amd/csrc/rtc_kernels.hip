@@ -645,7 +645,7 @@ DEV V3 normal_at(const DScene &s, const DPrim &p, V3 world_point, double u, doub
 //      vector cache, one 144-byte record per test.
 // Template flags remove state a scene does not need: GROUPS (any primitive has an ancestor group: ray cache
 // in group space, chain walks), PATTERNS (any material has a pattern).
-template <bool STATS, bool GROUPS, bool PATTERNS, bool PERSISTENT>
+template <bool STATS, bool GROUPS, bool PATTERNS, bool PERSISTENT, bool QNODES>
 __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DRenderParams prm,
                                                                      double *__restrict__ out,
                                                                      unsigned long long *__restrict__ stats,
@@ -901,6 +901,12 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     } while (0)
                 const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
                 const double lo = (T.mode == MODE_CONTAINER) ? -inf : 0.;
+                // slab plane of cell index q along axis a: t = (org + q * cell - o) / d = q * (cell / d) + (org / d + oi)
+                // (f32 nodes: the planes themselves, t = plane * inv_d + oi)
+                const V3 q_a = QNODES ? mk(s.q_cell[0] * inv_d.x, s.q_cell[1] * inv_d.y, s.q_cell[2] * inv_d.z) : inv_d;
+                const V3 q_b = QNODES ? mk(fma(s.q_org[0], inv_d.x, oi.x), fma(s.q_org[1], inv_d.y, oi.y),
+                                           fma(s.q_org[2], inv_d.z, oi.z))
+                                      : oi;
                 for (int step = 0; step < RTC_STEPS_PER_CHECK && in_pass; step++) {
                     if (pos < end) {
                         const DLeaf &L = s.leaves[pos++];
@@ -933,15 +939,25 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     }
                     // descend until a leaf is reached (bounded: the check above runs again after a few nodes)
                     for (int d = 0; d < RTC_NODES_PER_STEP && ref >= 0; d++) {
-                        const DBvhNode &n = s.bvh[ref];
                         double tl, tr;
                         CNT(ST_BOX, 2);
                         // containers pass: a subtree of paired primitives (spheres) matters only where its box
                         // reaches the hit point -- a sphere wholly before the hit toggles in and out again
                         const bool cont = T.mode == MODE_CONTAINER;
-                        const bool hl = slab(n.lmin, n.lmax, inv_d, oi, (cont && (n.flags & 1)) ? T.lim : lo, T.lim, tl);
-                        const bool hr = slab(n.rmin, n.rmax, inv_d, oi, (cont && (n.flags & 2)) ? T.lim : lo, T.lim, tr);
-                        const int cl = n.left, cr = n.right;
+                        const unsigned flags = cont ? s.node_flags[ref] : 0u;
+                        bool hl, hr;
+                        int cl, cr;
+                        if (QNODES) {
+                            const DBvhNodeQ &n = s.bvh_q[ref];
+                            hl = slab(n.lmin, n.lmax, q_a, q_b, (flags & 1u) ? T.lim : lo, T.lim, tl);
+                            hr = slab(n.rmin, n.rmax, q_a, q_b, (flags & 2u) ? T.lim : lo, T.lim, tr);
+                            cl = n.left, cr = n.right;
+                        } else {
+                            const DBvhNode &n = s.bvh[ref];
+                            hl = slab(n.lmin, n.lmax, q_a, q_b, (flags & 1u) ? T.lim : lo, T.lim, tl);
+                            hr = slab(n.rmin, n.rmax, q_a, q_b, (flags & 2u) ? T.lim : lo, T.lim, tr);
+                            cl = n.left, cr = n.right;
+                        }
                         if (hl && hr) {
                             const bool left_first = tl <= tr;
                             RTC_PUSH(left_first ? cr : cl);
@@ -1197,7 +1213,7 @@ static unsigned resident_waves(K kernel, unsigned n_cu) {
     return n_cu * (unsigned)per_cu;
 }
 
-template <bool STATS, bool GROUPS, bool PATTERNS>
+template <bool STATS, bool GROUPS, bool PATTERNS, bool QNODES>
 static void launch_variant(const DScene &scene, DRenderParams &params, double *d_rgb, unsigned long long *ds,
                            unsigned *d_work, unsigned n_cu, hipStream_t st) {
     const unsigned tiles = params.tiles_x * params.tiles_y;
@@ -1206,21 +1222,30 @@ static void launch_variant(const DScene &scene, DRenderParams &params, double *d
     // (best when some pixels grow ray trees thousands of rays deep)
     if (params.persistent) {
         static unsigned cap = 0;
-        if (!cap) cap = resident_waves(k_render<STATS, GROUPS, PATTERNS, true>, n_cu);
+        if (!cap) cap = resident_waves(k_render<STATS, GROUPS, PATTERNS, true, QNODES>, n_cu);
         const unsigned waves = tiles < cap ? tiles : cap;
         static const unsigned refill_env = getenv("RTC_REFILL_MIN") ? (unsigned)atoi(getenv("RTC_REFILL_MIN")) : 0u;
         params.refill_min = refill_env ? refill_env : RTC_REFILL_MIN;
         params.dyn_base = waves;  // wave b renders tile b first
         static const unsigned stay_env = getenv("RTC_STAY_MIN") ? (unsigned)atoi(getenv("RTC_STAY_MIN")) : 0u;
         params.stay_min = stay_env ? stay_env : RTC_STAY_MIN;
-        hipLaunchKernelGGL((k_render<STATS, GROUPS, PATTERNS, true>), dim3(waves), dim3(RTC_WAVE), 0, st, scene, params,
-                           d_rgb, ds, d_work);
+        hipLaunchKernelGGL((k_render<STATS, GROUPS, PATTERNS, true, QNODES>), dim3(waves), dim3(RTC_WAVE), 0, st, scene,
+                           params, d_rgb, ds, d_work);
     } else {
         params.refill_min = RTC_WAVE;
         params.dyn_base = tiles;
-        hipLaunchKernelGGL((k_render<STATS, GROUPS, PATTERNS, false>), dim3(tiles), dim3(RTC_WAVE), 0, st, scene, params,
-                           d_rgb, ds, d_work);
+        hipLaunchKernelGGL((k_render<STATS, GROUPS, PATTERNS, false, QNODES>), dim3(tiles), dim3(RTC_WAVE), 0, st, scene,
+                           params, d_rgb, ds, d_work);
     }
+}
+
+template <bool STATS, bool GROUPS, bool PATTERNS>
+static void launch_nodes(const DScene &scene, DRenderParams &params, double *d_rgb, unsigned long long *ds,
+                         unsigned *d_work, unsigned n_cu, hipStream_t st) {
+    if (scene.quantized_nodes)
+        launch_variant<STATS, GROUPS, PATTERNS, true>(scene, params, d_rgb, ds, d_work, n_cu, st);
+    else
+        launch_variant<STATS, GROUPS, PATTERNS, false>(scene, params, d_rgb, ds, d_work, n_cu, st);
 }
 
 int launch_render(const DScene &scene, const DRenderParams &params_in, double *d_rgb, uint64_t *d_stats,
@@ -1236,13 +1261,13 @@ int launch_render(const DScene &scene, const DRenderParams &params_in, double *d
     }
     unsigned long long *ds = (unsigned long long *)d_stats;
     if (collect_stats)
-        launch_variant<true, true, true>(scene, params, d_rgb, ds, d_work, n_cu, st);
+        launch_nodes<true, true, true>(scene, params, d_rgb, ds, d_work, n_cu, st);
     else if (scene.any_pattern)
-        launch_variant<false, true, true>(scene, params, d_rgb, ds, d_work, n_cu, st);
+        launch_nodes<false, true, true>(scene, params, d_rgb, ds, d_work, n_cu, st);
     else if (scene.any_group)
-        launch_variant<false, true, false>(scene, params, d_rgb, ds, d_work, n_cu, st);
+        launch_nodes<false, true, false>(scene, params, d_rgb, ds, d_work, n_cu, st);
     else
-        launch_variant<false, false, false>(scene, params, d_rgb, ds, d_work, n_cu, st);
+        launch_nodes<false, false, false>(scene, params, d_rgb, ds, d_work, n_cu, st);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("kernel launch failed: %s", hipGetErrorString(e));

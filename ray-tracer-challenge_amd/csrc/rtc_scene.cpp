@@ -487,7 +487,8 @@ static float f32_up(double v) {
 }
 
 void Scene::build_bvh() {
-    bvh.clear(), bvh_prims.clear();
+    bvh.clear(), bvh_q.clear(), bvh_prims.clear(), bvh_flags.clear();
+    quantized_nodes = false;
     bvh_max_depth = 0, bvh_max_leaf = 0;
     root_ref = 0;
     for (int k = 0; k < 3; k++) root_min[k] = root_max[k] = 0.0;
@@ -550,18 +551,46 @@ void Scene::build_bvh() {
                 }
         }
         bvh.resize(next);
+        bvh_flags.assign(next, 0);
+        // quantisation frame: the root box cut into 65535 cells per axis
+        for (int k = 0; k < 3; k++) {
+            q_org[k] = root_min[k];
+            double cell = (root_max[k] - root_min[k]) / 65535.0;
+            if (!(cell > 0.0)) cell = 1e-300;
+            while (q_org[k] + 65535.0 * cell < root_max[k]) cell = std::nextafter(cell, INF);
+            q_cell[k] = cell;
+        }
+        auto q_down = [&](double v, int k) -> uint16_t {
+            double q = std::floor((v - q_org[k]) / q_cell[k]);
+            q = std::max(0.0, std::min(65535.0, q));
+            while (q > 0.0 && q_org[k] + q * q_cell[k] > v) q -= 1.0;  // the division rounds: step outward
+            return (uint16_t)q;
+        };
+        auto q_up = [&](double v, int k) -> uint16_t {
+            double q = std::ceil((v - q_org[k]) / q_cell[k]);
+            q = std::max(0.0, std::min(65535.0, q));
+            while (q < 65535.0 && q_org[k] + q * q_cell[k] < v) q += 1.0;
+            return (uint16_t)q;
+        };
+        // hierarchies beyond 1 MB of f32 nodes are stored quantised (rtc_types.h)
+        quantized_nodes = (size_t)next * sizeof(DBvhNode) > (1u << 20);
+        bvh_q.resize(quantized_nodes ? next : 0);
         for (int t : queue) {
             const BuildNode &n = b.nodes[t];
             const BuildNode &l = b.nodes[n.left], &r = b.nodes[n.right];
             DBvhNode d{};
+            DBvhNodeQ q{};
             for (int k = 0; k < 3; k++) {
                 d.lmin[k] = f32_down(l.b.lo[k]), d.lmax[k] = f32_up(l.b.hi[k]);
                 d.rmin[k] = f32_down(r.b.lo[k]), d.rmax[k] = f32_up(r.b.hi[k]);
+                q.lmin[k] = q_down(l.b.lo[k], k), q.lmax[k] = q_up(l.b.hi[k], k);
+                q.rmin[k] = q_down(r.b.lo[k], k), q.rmax[k] = q_up(r.b.hi[k], k);
             }
-            d.left = (l.left >= 0) ? new_index[n.left] : leaf_ref(l);
-            d.right = (r.left >= 0) ? new_index[n.right] : leaf_ref(r);
-            d.flags = (paired[n.left] ? 1 : 0) | (paired[n.right] ? 2 : 0);
+            q.left = d.left = (l.left >= 0) ? new_index[n.left] : leaf_ref(l);
+            q.right = d.right = (r.left >= 0) ? new_index[n.right] : leaf_ref(r);
+            bvh_flags[new_index[t]] = (uint8_t)((paired[n.left] ? 1 : 0) | (paired[n.right] ? 2 : 0));
             bvh[new_index[t]] = d;
+            if (quantized_nodes) bvh_q[new_index[t]] = q;
         }
     }
     bvh_prims = order;
@@ -625,7 +654,14 @@ int Scene::upload(int dev) {
     if ((rc = upload_vec(*this, dmaterials, dscene.materials))) return rc;
     if ((rc = upload_vec(*this, lights, dscene.lights))) return rc;
     if ((rc = upload_vec(*this, dpatterns, dscene.patterns))) return rc;
-    if ((rc = upload_vec(*this, bvh, dscene.bvh))) return rc;
+    if (quantized_nodes) {
+        if ((rc = upload_vec(*this, bvh_q, dscene.bvh_q))) return rc;
+    } else {
+        if ((rc = upload_vec(*this, bvh, dscene.bvh))) return rc;
+    }
+    dscene.quantized_nodes = quantized_nodes ? 1 : 0;
+    if ((rc = upload_vec(*this, bvh_flags, dscene.node_flags))) return rc;
+    for (int k = 0; k < 3; k++) dscene.q_org[k] = q_org[k], dscene.q_cell[k] = q_cell[k];
     {
         std::vector<int32_t> list(unbounded);
         list.insert(list.end(), bvh_prims.begin(), bvh_prims.end());

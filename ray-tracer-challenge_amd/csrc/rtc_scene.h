@@ -64,7 +64,11 @@ struct Scene {
     std::vector<DTri> tris;
     std::vector<DMaterial> dmaterials;
     std::vector<DPattern> dpatterns;
-    std::vector<DBvhNode> bvh;
+    std::vector<DBvhNode> bvh;     // f32 nodes; bvh_q holds the same tree quantised when quantized_nodes
+    std::vector<DBvhNodeQ> bvh_q;
+    bool quantized_nodes = false;
+    std::vector<uint8_t> bvh_flags;
+    double q_org[3] = {0, 0, 0}, q_cell[3] = {1, 1, 1};
     std::vector<int32_t> bvh_prims;
     std::vector<int32_t> unbounded;
     std::vector<Bounds> prim_bounds;  // world-space, padded; only meaningful for bounded prims

@@ -6,8 +6,8 @@
 //   DPrim[]     one per leaf shape in depth-first (== reference traversal) order, 72 B
 //   DTri[]      triangle payloads (p1, e1, e2, n1..n3), 144 B
 //   DMaterial[] 96 B, DLight[] 136 B, DPattern[] 160 B
-//   DBvhNode[]  64 B internal nodes of the binary BVH over the bounded primitives (breadth-first order),
-//               each holding BOTH children's boxes in outward-rounded f32
+//   DBvhNode[] / DBvhNodeQ[]  64 B (f32) or 32 B (16-bit quantised) internal nodes of the binary BVH over the
+//               bounded primitives (breadth-first order), each holding BOTH children's boxes
 //   DLeaf[]     intersection-loop records: unbounded primitives (tested for every ray) followed by the BVH
 //               leaves' primitive runs; a second copy in primitive order serves brute-force mode
 #pragma once
@@ -92,18 +92,27 @@ struct DPattern {
     double inv[12];
 };
 
-// One per INTERNAL node of the binary BVH (64 B = half a cache line): both children's padded world-space boxes
-// live in the parent so a traversal step costs a single 64-byte fetch -- four 16-byte loads per lane; incoherent
-// rays pay one L1 tag look-up per lane per load, which is what bounds the traversal, so the boxes are stored
-// in f32, rounded OUTWARD (they are culling volumes of this build, not reference arithmetic; the slab test
-// itself runs in f64).  Child references: >= 0 is the index of another internal node; < 0 encodes a leaf as
-// ~((first << 3) | (count - 1)) with `first` an offset into DScene::leaves.
+// One per INTERNAL node of the binary BVH: both children's padded world-space boxes live in the parent, so a
+// traversal step costs a single fetch.  The boxes are culling volumes of this build, not reference arithmetic; the
+// slab test runs in f64 on the decoded planes.  Two encodings, chosen per scene at commit:
+//   DBvhNode  (64 B) f32 planes rounded OUTWARD -- small hierarchies (they stay in L2 anyway; cheapest decode);
+//   DBvhNodeQ (32 B) 16-bit cell indices in ONE frame for the whole hierarchy (DScene::q_org / q_cell: the root box
+//             cut into 65535 cells per axis), rounded OUTWARD -- large hierarchies: incoherent rays make traversal
+//             a chain of dependent cache misses whose cost is set by how much of the tree stays in the XCD's 4 MB
+//             L2 (stress scene: 6.6 MB -> 3.3 MB of nodes, 3.73 s -> 3.13 s per 4K frame).
+// Child references: >= 0 is the index of another internal node; < 0 encodes a leaf as
+// ~((first << 3) | (count - 1)) with `first` an offset into DScene::leaves.  The "paired" flags of the children
+// (see Scene::build_bvh) live in DScene::node_flags, read by the containers pass only.
 struct DBvhNode {
     float lmin[3], lmax[3];
     float rmin[3], rmax[3];
     int32_t left, right;
-    int32_t flags;  // bit 0 / 1: the left / right subtree holds "paired" primitives only (see Scene::build_bvh)
-    int32_t pad;
+    int32_t pad[2];
+};
+struct DBvhNodeQ {
+    uint16_t lmin[3], lmax[3];
+    uint16_t rmin[3], rmax[3];
+    int32_t left, right;
 };
 
 struct DCamera {
@@ -122,7 +131,10 @@ struct DScene {
     const DMaterial *materials;
     const DLight *lights;
     const DPattern *patterns;
-    const DBvhNode *bvh;
+    const DBvhNode *bvh;        // one of bvh / bvh_q is set (quantized_nodes)
+    const DBvhNodeQ *bvh_q;
+    const uint8_t *node_flags;  // per node: bit 0 / 1 = the left / right subtree holds "paired" primitives only
+    double q_org[3], q_cell[3]; // box plane along axis a = q_org[a] + q * q_cell[a]
     const DLeaf *leaves;       // [0, n_unbounded): primitives tested for every ray; then the BVH leaves' runs
     const DLeaf *leaves_all;   // DLeaf records in primitive order (brute-force mode)
     double root_min[3], root_max[3];
@@ -131,6 +143,7 @@ struct DScene {
     int32_t all_cast_shadow;  // 1 if every material has casts_shadow: shadow rays may stop at any hit
     int32_t any_pattern;
     int32_t any_group;        // 1 if some primitive sits inside a group (ancestor transforms exist)
+    int32_t quantized_nodes;  // 1: bvh_q, 0: bvh
 };
 
 struct DRenderParams {
