@@ -642,7 +642,7 @@ DEV V3 normal_at(const DScene &s, const DPrim &p, V3 world_point, double u, doub
 //      walks it in lockstep, so the records come through the scalar cache into SGPRs and the per-type
 //      switch is a scalar branch;
 //   2. ordered traversal of the binary BVH with the per-lane stack in LDS; leaf records come through the
-//      vector cache, one 144-byte record per test.
+//      vector cache, one 128-byte record (one cache line) per test.
 // Template flags remove state a scene does not need: GROUPS (any primitive has an ancestor group: ray cache
 // in group space, chain walks), PATTERNS (any material has a pattern).
 template <bool STATS, bool GROUPS, bool PATTERNS, bool PERSISTENT, bool QNODES>

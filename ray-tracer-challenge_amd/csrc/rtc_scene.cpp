@@ -669,16 +669,16 @@ int Scene::upload(int dev) {
         auto make_leaf = [&](int32_t pi) {
             const DPrim &p = prims[pi];
             DLeaf l{};
-            l.type = p.type, l.prim = pi, l.closed = p.closed;
+            l.type = (uint8_t)p.type, l.prim = pi, l.closed = (uint8_t)p.closed;
             l.minimum = p.minimum, l.maximum = p.maximum;
             l.anc_off = p.chain_off;
             l.anc_id = prim_anc_id[pi];
             if (p.type >= PT_TRIANGLE) {
-                l.anc_len = p.chain_len;
+                l.anc_len = (uint16_t)p.chain_len;
                 const DTri &t = tris[p.tri];
                 for (int i = 0; i < 3; i++) l.a[i] = t.p1[i], l.a[3 + i] = t.e1[i], l.a[6 + i] = t.e2[i];
             } else {
-                l.anc_len = p.chain_len - 1;
+                l.anc_len = (uint16_t)(p.chain_len - 1);
                 const DXform &x = xforms[chains[p.chain_off + p.chain_len - 1]];
                 for (int i = 0; i < 12; i++) l.a[i] = x.inv[i];
             }

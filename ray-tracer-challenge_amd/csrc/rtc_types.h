@@ -44,22 +44,22 @@ struct DPrim {
     double plane_normal[3];
 };
 
-// Intersection-loop record (144 B), one per primitive and per list position: everything a ray/primitive test
+// Intersection-loop record (128 B), one per primitive and per list position: everything a ray/primitive test
 // needs sits in ONE record, so a test costs a single memory round trip (the uniform list is read through the
 // scalar cache, BVH leaves through the vector cache).  `a` holds rows 0..2 of inverse(T_own) for analytic
 // shapes and p1,e1,e2 for triangles (whose own transform is the identity and is skipped, shape.rs:1505-1509).
 // anc_* describe the ANCESTOR (group) transforms only, applied root first before `a`.
-struct DLeaf {
-    int32_t type;
+struct DLeaf {  // 128 B, 128-byte aligned: one test = one cache line
+    uint8_t type;
+    uint8_t closed;
+    uint16_t anc_len;  // number of enclosing groups
     int32_t prim;      // flattened (depth-first) primitive index: identity, tie-break order, shading lookup
-    int32_t anc_len;   // number of enclosing groups
     int32_t anc_off;   // into chains[]
     int32_t anc_id;    // equal ids <=> same ancestor chain (ray-in-group-space cache key); -1 when anc_len == 0
-    int32_t closed;
-    int32_t pad[2];
     double minimum, maximum;
     double a[12];
 };
+static_assert(sizeof(DLeaf) == 128, "DLeaf must fill exactly one 128-byte line");
 
 struct DTri {
     double p1[3], e1[3], e2[3];
