@@ -698,7 +698,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     int cache_id = -1;  // ancestor chain the cached ray is expressed in (GROUPS)
     Ray cache_ray = ray;
     // ---- shading context (valid from the closest hit until the last shadow ray of that hit) ----
-    int h_prim = -1;
+    int h_prim = -1, h_mat = 0;  // hit primitive and its material index (read once per hit)
     int li = 0;
     unsigned su = 0, sv = 0, unshadowed = 0;
 
@@ -1009,7 +1009,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 next_ray = true;
             } else {
                 const DPrim &p = s.prims[T.prim];
-                const DMaterial &m = s.materials[p.material];
+                h_mat = p.material;
+                const DMaterial &m = s.materials[h_mat];
                 // Intersection::prepare_computations, intersection.rs:123-148
                 h_prim = T.prim;
                 const V3 h_point = ray.o + ray.d * T.lim;
@@ -1033,7 +1034,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 begin_lights = true;
             }
         } else if (T.mode == MODE_CONTAINER) {
-            const double ri_hit = s.materials[s.prims[h_prim].material].refractive_index;
+            const double ri_hit = s.materials[h_mat].refractive_index;
             const double ri_other =
                 (T.c_best_prim >= 0) ? s.materials[s.prims[T.c_best_prim].material].refractive_index : 1.;
             double n1, n2;
@@ -1072,11 +1073,10 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 inten = shadowed ? 0. : 1.;
             }
             if (have) {
-                const DPrim &p = s.prims[h_prim];
-                const DMaterial &m = s.materials[p.material];
+                const DMaterial &m = s.materials[h_mat];
                 const V3 over = ray.o;  // the shadow ray starts at over_point (world.rs:50, 79)
                 V3 col = ld3(m.color);
-                if (PATTERNS && m.pattern >= 0) col = pattern_at_shape(s, m.pattern, p, over);
+                if (PATTERNS && m.pattern >= 0) col = pattern_at_shape(s, m.pattern, s.prims[h_prim], over);
                 const V3 lightv = lt.is_area ? normalize(ld3(lt.position) - over) : ray.d;
                 const V3 c = lighting(m, col, lightv, ld3(lt.intensity), unpark3(pk, PK_EYE), unpark3(pk, PK_NORMAL), inten);
                 CNT(ST_LIGHT, 1);
@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         if (finish) {
             // World::shade_hit (world.rs:42-76).  The reference evaluates reflected_color/refracted_color inside
             // the per-light loop (Q3), i.e. adds them n_lights times: that factor goes into the child's weight.
-            const DMaterial &m = s.materials[s.prims[h_prim].material];
+            const DMaterial &m = s.materials[h_mat];
             const double w = pk[PK_W * RTC_WAVE];
             park3(pk, PK_COLOR, unpark3(pk, PK_COLOR) + unpark3(pk, PK_SURFACE) * w);
             next_ray = true;
