@@ -514,7 +514,7 @@ struct Counters {
 
 struct Pending {
     V3 o, d;
-    double w, mult;
+    double w;
     int remaining;
 };
 
@@ -680,6 +680,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     double mult = 1.;  // STATS only: how many times the reference traces this ray (Q3)
     int remaining = 0;
     Pending pend[RTC_MAX_DEPTH_STACK];
+    double pend_mult[STATS ? RTC_MAX_DEPTH_STACK : 1];  // STATS only: `mult` of the waiting rays
     int sp = 0;
     int rays = 0;
     const double nl = (double)s.n_lights;
@@ -1105,46 +1106,56 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 const bool refl = m.reflectivity != 0.;
                 const bool refr = m.transparency != 0.;
                 if (refl || refr) {
-                    const V3 h_point = unpark3(pk, PK_POINT), h_normal = unpark3(pk, PK_NORMAL);
+                    // the parked context is read where it is used (volatile: one LDS read per use) so that
+                    // nothing of it is held in registers -- or spilled to scratch -- across the square roots
+                    const V3 h_normal = unpark3(pk, PK_NORMAL);
                     const V3 h_eye = unpark3(pk, PK_EYE);
-                    const double h_n1 = pk[PK_N1 * RTC_WAVE], h_n2 = pk[PK_N2 * RTC_WAVE];
                     double kr = 1., kt = 1.;
                     if (m.reflectivity > 0. && m.transparency > 0.) {
-                        const double r = schlick(h_n1, h_n2, h_eye, h_normal);
+                        const double r = schlick(pk[PK_N1 * RTC_WAVE], pk[PK_N2 * RTC_WAVE], h_eye, h_normal);
                         CNT(ST_SCHLICK, 1);
                         kr = r;
                         kt = 1. - r;
                     }
+                    bool refracted = false;
                     if (refr) {
                         // refracted_color, world.rs:108-147
-                        const double n_ratio = h_n1 / h_n2;
+                        const double n_ratio = pk[PK_N1 * RTC_WAVE] / pk[PK_N2 * RTC_WAVE];
                         const double cos_i = dot(h_eye, h_normal);
                         const double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
                         CNT(ST_REFRACT, 1);
                         if (!(sin2_t > 1.)) {
-                            const double cos_t = sqrt(1. - sin2_t);
-                            Pending q;
-                            q.o = h_point - h_normal * RTC_EPS;  // under_point
-                            q.d = h_normal * (n_ratio * cos_i - cos_t) - h_eye * n_ratio;
-                            q.w = w * (nl * (m.transparency * kt));
-                            q.mult = STATS ? mult * nl : 0.;
-                            q.remaining = remaining;  // Q2: not decremented (world.rs:142)
                             if (sp < RTC_MAX_DEPTH_STACK) {
-                                pend[sp] = q;
-                                sp++;
+                                // written straight into its stack slot: nothing of it is held across the reflection
+                                const double cos_t = sqrt(1. - sin2_t);
+                                Pending &q = pend[sp];
+                                q.o = unpark3(pk, PK_POINT) - h_normal * RTC_EPS;  // under_point
+                                q.d = h_normal * (n_ratio * cos_i - cos_t) - h_eye * n_ratio;
+                                q.w = w * (nl * (m.transparency * kt));
+                                q.remaining = remaining;  // Q2: not decremented (world.rs:142)
+                                if (STATS) pend_mult[sp] = mult * nl;
+                                refracted = true;
                             } else {
                                 CNT(ST_OVERFLOW, 1);
                             }
                         }
                     }
                     if (refl) {
+                        // both children: the refracted ray waits in the stack while the reflected one is traced
+                        if (refracted) sp++;
                         // reflected_color, world.rs:93-106
-                        const V3 d_in = -h_eye;
-                        ray.o = h_point + h_normal * RTC_EPS;  // over_point
-                        ray.d = reflect(d_in, h_normal);
+                        ray.o = unpark3(pk, PK_POINT) + h_normal * RTC_EPS;  // over_point
+                        ray.d = reflect(-h_eye, h_normal);
                         pk[PK_W * RTC_WAVE] = w * (nl * (m.reflectivity * kr));
-                        if (STATS) mult = mult * nl;
                         remaining -= 1;
+                    } else if (refracted) {
+                        // the only child: it is the next ray
+                        const Pending &q = pend[sp];
+                        ray.o = q.o, ray.d = q.d;
+                        pk[PK_W * RTC_WAVE] = q.w;
+                    }
+                    if (refl || refracted) {
+                        if (STATS) mult = mult * nl;
                         next_ray = false;
                         T.mode = MODE_CLOSEST;
                         T.lim = inf, T.prim = -1;
@@ -1163,7 +1174,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 const Pending q = pend[sp];
                 ray.o = q.o, ray.d = q.d, remaining = q.remaining;
                 pk[PK_W * RTC_WAVE] = q.w;
-                if (STATS) mult = q.mult;
+                if (STATS) mult = pend_mult[sp];
                 T.mode = MODE_CLOSEST;
                 T.lim = inf, T.prim = -1;
                 CNT(ST_SECONDARY, 1);
