@@ -919,6 +919,29 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     const unsigned n_leaf = (unsigned)__popcll(__ballot(at_leaf));
                     const unsigned n_node = (unsigned)__popcll(__ballot(!at_leaf));
                     if (at_leaf && n_node != 0u && n_leaf * prm.leaf_den < n_leaf + n_node) continue;
+                    if (at_leaf && QNODES && (pos & RTC_LEAF_COMPACT)) {
+                        // sphere with a diagonal + translation inverse: 64-byte record, the off-diagonal zeros are
+                        // rebuilt with their signs and the arithmetic is the general sphere's (same bits)
+                        const DLeafS &L = s.leaves_s[(pos++) & (RTC_LEAF_COMPACT - 1)];
+                        double a[12];
+                        const unsigned long long zs = L.zsign;
+                        a[0] = L.d[0], a[5] = L.d[1], a[10] = L.d[2];
+                        a[3] = L.t[0], a[7] = L.t[1], a[11] = L.t[2];
+                        a[1] = __longlong_as_double((long long)((zs & 1ull) << 63));
+                        a[2] = __longlong_as_double((long long)(((zs >> 1) & 1ull) << 63));
+                        a[4] = __longlong_as_double((long long)(((zs >> 2) & 1ull) << 63));
+                        a[6] = __longlong_as_double((long long)(((zs >> 3) & 1ull) << 63));
+                        a[8] = __longlong_as_double((long long)(((zs >> 4) & 1ull) << 63));
+                        a[9] = __longlong_as_double((long long)(((zs >> 5) & 1ull) << 63));
+                        CNT(ST_XFORM, 1);
+                        CNT(ST_PRIM0 + PT_SPHERE, 1);
+                        Ray q;
+                        q.o = xf_point((const double *)a, ray.o), q.d = xf_vector((const double *)a, ray.d);
+                        isect_sphere(q, T, L.prim);
+                        end_prim(T, L.prim);
+                        if (any_hit && T.prim >= 0) in_pass = false;
+                        continue;
+                    }
                     if (at_leaf) {
                         const DLeaf &L = s.leaves[pos++];
                         // Ray::transform down the ancestor chain, root first (shape.rs:2035).  Primitives of one

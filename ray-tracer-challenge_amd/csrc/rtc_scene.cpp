@@ -487,7 +487,7 @@ static float f32_up(double v) {
 }
 
 void Scene::build_bvh() {
-    bvh.clear(), bvh_q.clear(), bvh_prims.clear(), bvh_flags.clear();
+    bvh.clear(), bvh_q.clear(), bvh_prims.clear(), bvh_flags.clear(), compact_prims.clear();
     quantized_nodes = false;
     bvh_max_depth = 0, bvh_max_leaf = 0;
     root_ref = 0;
@@ -509,6 +509,9 @@ void Scene::build_bvh() {
         b.max_depth = m.max_depth;
     }
     bvh_max_depth = b.max_depth;
+    // Leaf primitives in ascending flattened index (deterministic visiting order inside a leaf).
+    for (const BuildNode &n : b.nodes)
+        if (n.left < 0) std::sort(order.begin() + n.first, order.begin() + n.first + n.count);
 
     // "paired" subtrees hold only primitives whose records always come in pairs on both sides of their interior
     // (spheres: two records or none, shape.rs:218-239).  Such a primitive can only be an open container at the
@@ -528,8 +531,22 @@ void Scene::build_bvh() {
     // Breadth-first relayout of the INTERNAL nodes only; every node stores both children's boxes.
     // Leaves become child references ~((first << 3) | (count - 1)), `first` relative to the leaf-record list (unbounded primitives first).
     const int32_t base = (int32_t)unbounded.size();
+    // a sphere outside any group whose inverse transform is diagonal + translation fits a 64-byte DLeafS
+    auto compact_sphere = [&](int32_t pi) {
+        const DPrim &p = prims[pi];
+        if (p.type != PT_SPHERE || p.chain_len != 1) return false;
+        const double *a = xforms[chains[p.chain_off]].inv;
+        return a[1] == 0.0 && a[2] == 0.0 && a[4] == 0.0 && a[6] == 0.0 && a[8] == 0.0 && a[9] == 0.0;
+    };
     auto leaf_ref = [&](const BuildNode &n) -> int32_t {
         bvh_max_leaf = std::max<uint32_t>(bvh_max_leaf, (uint32_t)n.count);
+        bool compact = quantized_nodes;  // large hierarchies only: small ones stay in L2 whatever the record size
+        for (int q = 0; q < n.count && compact; q++) compact = compact_sphere(order[n.first + q]);
+        if (compact) {
+            const int32_t first = (int32_t)compact_prims.size();
+            for (int q = 0; q < n.count; q++) compact_prims.push_back(order[n.first + q]);
+            return ~(((RTC_LEAF_COMPACT | first) << 3) | (n.count - 1));
+        }
         return ~(((base + n.first) << 3) | (n.count - 1));
     };
     for (int k = 0; k < 3; k++) root_min[k] = b.nodes[0].b.lo[k], root_max[k] = b.nodes[0].b.hi[k];
@@ -594,9 +611,6 @@ void Scene::build_bvh() {
         }
     }
     bvh_prims = order;
-    // Leaf primitives in ascending flattened index (deterministic visiting order inside a leaf).
-    for (const BuildNode &n : b.nodes)
-        if (n.left < 0) std::sort(bvh_prims.begin() + n.first, bvh_prims.begin() + n.first + n.count);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -689,6 +703,19 @@ int Scene::upload(int dev) {
         for (size_t i = 0; i < prims.size(); i++) la[i] = make_leaf((int32_t)i);
         if ((rc = upload_vec(*this, lv, dscene.leaves))) return rc;
         if ((rc = upload_vec(*this, la, dscene.leaves_all))) return rc;
+        std::vector<DLeafS> ls(compact_prims.size());
+        for (size_t i = 0; i < compact_prims.size(); i++) {
+            const DPrim &p = prims[compact_prims[i]];
+            const double *a = xforms[chains[p.chain_off]].inv;
+            DLeafS &l = ls[i];
+            l = DLeafS{};
+            l.prim = compact_prims[i];
+            const int off_diag[6] = {1, 2, 4, 6, 8, 9};
+            for (int k = 0; k < 6; k++)
+                if (std::signbit(a[off_diag[k]])) l.zsign |= 1u << k;
+            for (int k = 0; k < 3; k++) l.d[k] = a[5 * k], l.t[k] = a[4 * k + 3];
+        }
+        if ((rc = upload_vec(*this, ls, dscene.leaves_s))) return rc;
     }
     for (int k = 0; k < 3; k++) dscene.root_min[k] = root_min[k], dscene.root_max[k] = root_max[k];
     dscene.root_ref = root_ref;
@@ -747,6 +774,10 @@ int Scene::commit(int dev) {
     }
     int rc = flatten();
     if (rc) return rc;
+    if (prims.size() >= (size_t)RTC_LEAF_COMPACT) {
+        set_error("%zu primitives: leaf references hold 27 bits", prims.size());
+        return RTC_ERR_INVALID;
+    }
     build_bvh();
     if (dev >= 0) {
         rc = upload(dev);

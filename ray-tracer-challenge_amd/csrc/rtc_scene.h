@@ -70,6 +70,7 @@ struct Scene {
     std::vector<uint8_t> bvh_flags;
     double q_org[3] = {0, 0, 0}, q_cell[3] = {1, 1, 1};
     std::vector<int32_t> bvh_prims;
+    std::vector<int32_t> compact_prims;  // primitives of the sphere-only leaf runs, in DScene::leaves_s order
     std::vector<int32_t> unbounded;
     std::vector<Bounds> prim_bounds;  // world-space, padded; only meaningful for bounded prims
     std::vector<uint8_t> prim_bounded;

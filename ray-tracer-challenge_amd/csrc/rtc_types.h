@@ -61,6 +61,21 @@ struct DLeaf {  // 128 B, 128-byte aligned: one test = one cache line
 };
 static_assert(sizeof(DLeaf) == 128, "DLeaf must fill exactly one 128-byte line");
 
+// Compact BVH-leaf record (64 B) for the commonest primitive of big scenes: a sphere outside any group whose
+// inverse transform is diagonal + translation (translation * scaling).  The six off-diagonal entries are +-0:
+// only their signs are kept, the kernel rebuilds the 3x4 matrix and runs the SAME arithmetic as for a DLeaf, so
+// results are bit-identical; what is saved is half of the leaf traffic (leaf records are what misses in L2).
+// Leaf runs made of such spheres only are stored in DScene::leaves_s; RTC_LEAF_COMPACT marks their references.
+struct DLeafS {
+    int32_t prim;
+    uint32_t zsign;  // bit k: off-diagonal entry k (row-major order a01 a02 a10 a12 a20 a21) is -0.0
+    double d[3];     // a00 a11 a22
+    double t[3];     // a03 a13 a23
+    uint32_t pad[2];
+};
+static_assert(sizeof(DLeafS) == 64, "DLeafS is half a cache line");
+#define RTC_LEAF_COMPACT (1 << 27)  // in the `first` field of a leaf reference / the kernel's leaf cursor
+
 struct DTri {
     double p1[3], e1[3], e2[3];
     double n1[3], n2[3], n3[3];  // flat triangles: n1 = precomputed face normal
@@ -101,7 +116,8 @@ struct DPattern {
 //             a chain of dependent cache misses whose cost is set by how much of the tree stays in the XCD's 4 MB
 //             L2 (stress scene: 6.6 MB -> 3.3 MB of nodes, 3.73 s -> 3.13 s per 4K frame).
 // Child references: >= 0 is the index of another internal node; < 0 encodes a leaf as
-// ~((first << 3) | (count - 1)) with `first` an offset into DScene::leaves.  The "paired" flags of the children
+// ~((first << 3) | (count - 1)) with `first` an offset into DScene::leaves (or RTC_LEAF_COMPACT | offset into
+// DScene::leaves_s).  The "paired" flags of the children
 // (see Scene::build_bvh) live in DScene::node_flags, read by the containers pass only.
 struct DBvhNode {
     float lmin[3], lmax[3];
@@ -137,6 +153,7 @@ struct DScene {
     double q_org[3], q_cell[3]; // box plane along axis a = q_org[a] + q * q_cell[a]
     const DLeaf *leaves;       // [0, n_unbounded): primitives tested for every ray; then the BVH leaves' runs
     const DLeaf *leaves_all;   // DLeaf records in primitive order (brute-force mode)
+    const DLeafS *leaves_s;    // compact records of sphere-only leaf runs (large hierarchies)
     double root_min[3], root_max[3];
     int32_t root_ref;          // child reference of the BVH root (valid when n_bounded > 0)
     int32_t n_prims, n_unbounded, n_bounded, n_bvh_nodes, n_lights, n_materials;
