@@ -864,7 +864,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 // ---- phase 2 set-up: ordered BVH traversal, leaves tested as they are reached ----
                 inv_d = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
                 oi = mk(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z);
-                pos = 0, end = 0, sb = 0;
+                pos = 0, end = 0;
+                stack[0] = RTC_NO_NODE, sb = 1;  // bottom of the stack: "pass finished"
                 double tn;
                 CNT(ST_BOX, 1);
                 if (slab(s.root_min, s.root_max, inv_d, oi, (T.mode == MODE_CONTAINER) ? -inf : 0., T.lim, tn)) {
@@ -900,8 +901,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
 #define RTC_POP(v)                                                                                   \
     do {                                                                                             \
         sb--;                                                                                        \
-        (v) = (sb < RTC_LDS_STACK) ? stack[sb * RTC_WAVE]                                            \
-                                   : deep_stack[(sb < RTC_BVH_STACK ? sb : RTC_BVH_STACK - 1) - RTC_LDS_STACK]; \
+        (v) = stack[(sb < RTC_LDS_STACK ? sb : RTC_LDS_STACK - 1) * RTC_WAVE];                       \
+        if (sb >= RTC_LDS_STACK) (v) = deep_stack[(sb < RTC_BVH_STACK ? sb : RTC_BVH_STACK - 1) - RTC_LDS_STACK]; \
     } while (0)
                 const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
                 const double lo = (T.mode == MODE_CONTAINER) ? -inf : 0.;
@@ -961,16 +962,10 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         if (any_hit && T.prim >= 0) in_pass = false;
                         continue;
                     }
-                    // ---- the node in hand, or the next one from the stack ----
+                    // ---- the node in hand, or the next one from the stack (whose bottom entry is RTC_NO_NODE: popping
+                    // it ends the pass, so an empty stack needs no test of its own) ----
                     int ref = cur;
-                    if (ref == RTC_NO_NODE) {
-                        if (sb > 0) {
-                            RTC_POP(ref);
-                        } else {
-                            in_pass = false;
-                            continue;
-                        }
-                    }
+                    if (ref == RTC_NO_NODE) RTC_POP(ref);
                     // descend until a leaf is reached (bounded: the check above runs again after a few nodes)
                     for (int d = 0; d < RTC_NODES_PER_STEP && ref >= 0; d++) {
                         double tl, tr;
@@ -982,7 +977,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         bool hl, hr;
                         int cl, cr;
                         if (QNODES) {
-                            const DBvhNodeQ &n = s.bvh_q[ref];
+                            const DBvhNodeQ n = s.bvh_q[ref];  // both halves requested before either is used
+                            __builtin_amdgcn_sched_barrier(0);
                             hl = slab(n.lmin, n.lmax, q_a, q_b, (flags & 1u) ? T.lim : lo, T.lim, tl);
                             hr = slab(n.rmin, n.rmax, q_a, q_b, (flags & 2u) ? T.lim : lo, T.lim, tr);
                             cl = n.left, cr = n.right;
@@ -992,24 +988,20 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                             hr = slab(n.rmin, n.rmax, q_a, q_b, (flags & 2u) ? T.lim : lo, T.lim, tr);
                             cl = n.left, cr = n.right;
                         }
-                        if (hl && hr) {
-                            const bool left_first = tl <= tr;
-                            RTC_PUSH(left_first ? cr : cl);
-                            ref = left_first ? cl : cr;
-                        } else if (hl) {
-                            ref = cl;
-                        } else if (hr) {
-                            ref = cr;
-                        } else if (sb > 0) {
+                        // near child first, the far one waits on the stack (selects, not a branch per case)
+                        const bool left_first = tl <= tr;
+                        const bool take_left = hl && (!hr || left_first);
+                        if (hl && hr) RTC_PUSH(left_first ? cr : cl);
+                        if (hl || hr)
+                            ref = take_left ? cl : cr;
+                        else
                             RTC_POP(ref);
-                        } else {
-                            in_pass = false;
-                            ref = RTC_NO_NODE;
-                            break;
-                        }
                     }
-                    if (ref >= 0 || ref == RTC_NO_NODE) {
-                        cur = ref;  // still an internal node (or finished): carry on at the next step
+                    if (ref >= 0) {
+                        cur = ref;  // still an internal node: carry on at the next step
+                    } else if (ref == RTC_NO_NODE) {
+                        in_pass = false;  // the stack's bottom entry: every subtree has been dealt with
+                        cur = RTC_NO_NODE;
                     } else {
                         const int code = ~ref;
                         pos = code >> 3;
