@@ -36,8 +36,12 @@ namespace rtc {
 #define RTC_MAX_DEPTH_STACK 8
 #define RTC_MAX_RAYS_PER_PIXEL 65536
 #define RTC_NO_NODE ((int)0x80000000)  // "no node in hand": the next step pops the stack
-#define RTC_STEPS_PER_CHECK 4         // traversal steps between two looks at the wave's occupancy
-#define RTC_NODES_PER_STEP 4          // BVH nodes one step may descend through
+#ifndef RTC_STEPS_PER_CHECK
+#define RTC_STEPS_PER_CHECK 8         // traversal steps between two looks at the wave's occupancy
+#endif
+#ifndef RTC_NODES_PER_STEP
+#define RTC_NODES_PER_STEP 2          // BVH nodes one step may descend through
+#endif
 #define RTC_SHARDS 8u  // tile counters of the persistent grid
 #ifndef RTC_STAY_MIN
 #define RTC_STAY_MIN 16  // waiting lanes (finished pass / free) at which a wave leaves the traversal loop to serve them
