@@ -139,28 +139,33 @@ struct DCamera {
 
 // Everything a kernel needs, passed by value as the kernel argument.
 struct DScene {
-    DCamera cam;
+    // The struct is the kernel argument: ~100 SGPRs fetched in blocks of up to 16 registers, and what does not
+    // fit is parked in VGPR lanes and brought back a whole block at a time.  The first 64 bytes are therefore
+    // exactly what the traversal loop dereferences, so that this block stays resident.
+    const DBvhNodeQ *bvh_q;     // one of bvh / bvh_q is set (quantized_nodes)
+    const uint8_t *node_flags;  // per node: bit 0 / 1 = the left / right subtree holds "paired" primitives only
+    const DLeaf *leaves;        // [0, n_unbounded): primitives tested for every ray; then the BVH leaves' runs
+    const DLeafS *leaves_s;     // compact records of sphere-only leaf runs (large hierarchies)
+    const DBvhNode *bvh;
     const DXform *xforms;
     const int32_t *chains;
-    const DPrim *prims;
     const DTri *tris;
+    // ---- shading ----
+    const DPrim *prims;
     const DMaterial *materials;
     const DLight *lights;
     const DPattern *patterns;
-    const DBvhNode *bvh;        // one of bvh / bvh_q is set (quantized_nodes)
-    const DBvhNodeQ *bvh_q;
-    const uint8_t *node_flags;  // per node: bit 0 / 1 = the left / right subtree holds "paired" primitives only
-    double q_org[3], q_cell[3]; // box plane along axis a = q_org[a] + q * q_cell[a]
-    const DLeaf *leaves;       // [0, n_unbounded): primitives tested for every ray; then the BVH leaves' runs
-    const DLeaf *leaves_all;   // DLeaf records in primitive order (brute-force mode)
-    const DLeafS *leaves_s;    // compact records of sphere-only leaf runs (large hierarchies)
-    double root_min[3], root_max[3];
-    int32_t root_ref;          // child reference of the BVH root (valid when n_bounded > 0)
+    const DLeaf *leaves_all;    // DLeaf records in primitive order (brute-force mode)
+    int32_t root_ref;           // child reference of the BVH root (valid when n_bounded > 0)
     int32_t n_prims, n_unbounded, n_bounded, n_bvh_nodes, n_lights, n_materials;
     int32_t all_cast_shadow;  // 1 if every material has casts_shadow: shadow rays may stop at any hit
     int32_t any_pattern;
     int32_t any_group;        // 1 if some primitive sits inside a group (ancestor transforms exist)
     int32_t quantized_nodes;  // 1: bvh_q, 0: bvh
+    int32_t pad0;
+    double q_org[3], q_cell[3]; // box plane along axis a = q_org[a] + q * q_cell[a]
+    double root_min[3], root_max[3];
+    DCamera cam;
 };
 
 struct DRenderParams {
