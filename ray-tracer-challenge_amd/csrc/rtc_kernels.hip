@@ -506,8 +506,10 @@ DEV bool slab(const F *bmin, const F *bmax, const V3 &inv_d, const V3 &oi, doubl
     tn = fmax(tn, fmin(t1, t2)), tf = fmin(tf, fmax(t1, t2));
     t1 = fma((double)bmin[2], inv_d.z, oi.z), t2 = fma((double)bmax[2], inv_d.z, oi.z);
     tn = fmax(tn, fmin(t1, t2)), tf = fmin(tf, fmax(t1, t2));
+    // [tn, tf] clipped to the ray segment [lo, hi] (lo <= hi always): one comparison instead of three
+    tn = fmax(tn, lo), tf = fmin(tf, hi);
     tnear = tn;
-    return tn <= tf && tn <= hi && tf >= lo;
+    return tn <= tf;
 }
 DEV double safe_rcp(double d) {
     const double r = __builtin_amdgcn_rcp(d);
