@@ -511,6 +511,26 @@ DEV bool slab(const F *bmin, const F *bmax, const V3 &inv_d, const V3 &oi, doubl
     tnear = tn;
     return tn <= tf;
 }
+// Quantised boxes: both children of a DBvhNodeQ against one ray.  The near / far plane of an axis is known from
+// the sign of the ray direction, so each plane index is picked out of the node's dwords by ONE v_perm_b32 with a
+// per-lane selector (extraction and near/far choice in a single instruction), and no min/max per axis is needed:
+// t(q) = q * q_a + q_b is monotonic in q, so the result equals min/max of the two planes' distances bit for bit.
+// Node dwords: d0 = min.x | min.y << 16, d1 = min.z | max.x << 16, d2 = max.y | max.z << 16.
+#define RTC_SEL_FLIP 0x0606u  // near selector ^ far selector, same for the three axes
+DEV unsigned near_selector_xz(double qa) { return qa >= 0. ? 0x0c0c0100u : 0x0c0c0706u; }  // perm(d1|d2, d0|d1)
+DEV unsigned near_selector_y(double qa) { return qa >= 0. ? 0x0c0c0302u : 0x0c0c0504u; }   // perm(d2, d0)
+DEV bool slab_q(unsigned d0, unsigned d1, unsigned d2, unsigned sx, unsigned sy, unsigned sz, const V3 &q_a,
+                const V3 &q_b, double lo, double hi, double &tnear) {
+    const double nx = (double)__builtin_amdgcn_perm(d1, d0, sx), fx = (double)__builtin_amdgcn_perm(d1, d0, sx ^ RTC_SEL_FLIP);
+    const double ny = (double)__builtin_amdgcn_perm(d2, d0, sy), fy = (double)__builtin_amdgcn_perm(d2, d0, sy ^ RTC_SEL_FLIP);
+    const double nz = (double)__builtin_amdgcn_perm(d2, d1, sz), fz = (double)__builtin_amdgcn_perm(d2, d1, sz ^ RTC_SEL_FLIP);
+    double tn = fma(nx, q_a.x, q_b.x), tf = fma(fx, q_a.x, q_b.x);
+    tn = fmax(tn, fma(ny, q_a.y, q_b.y)), tf = fmin(tf, fma(fy, q_a.y, q_b.y));
+    tn = fmax(tn, fma(nz, q_a.z, q_b.z)), tf = fmin(tf, fma(fz, q_a.z, q_b.z));
+    tn = fmax(tn, lo), tf = fmin(tf, hi);
+    tnear = tn;
+    return tn <= tf;
+}
 DEV double safe_rcp(double d) {
     const double r = __builtin_amdgcn_rcp(d);
     const double a = fmin(fabs(r), 1e30);  // d == 0 (or denormal): a huge finite slope keeps fma() NaN-free
@@ -918,6 +938,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 const V3 q_b = QNODES ? mk(fma(s.q_org[0], inv_d.x, oi.x), fma(s.q_org[1], inv_d.y, oi.y),
                                            fma(s.q_org[2], inv_d.z, oi.z))
                                       : oi;
+                const unsigned sel_x = near_selector_xz(q_a.x), sel_y = near_selector_y(q_a.y), sel_z = near_selector_xz(q_a.z);
                 for (int step = 0; step < RTC_STEPS_PER_CHECK && in_pass; step++) {
                     // A step is a primitive test for lanes standing at a leaf and a short descent for the others.
                     // The primitive test is the longer half: it only runs once enough lanes wait for it (or no
@@ -983,11 +1004,12 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         bool hl, hr;
                         int cl, cr;
                         if (QNODES) {
-                            const DBvhNodeQ n = s.bvh_q[ref];  // both halves requested before either is used
+                            const uint4 *np = (const uint4 *)(s.bvh_q + ref);
+                            const uint4 w0 = np[0], w1 = np[1];  // both halves requested before either is used
                             __builtin_amdgcn_sched_barrier(0);
-                            hl = slab(n.lmin, n.lmax, q_a, q_b, (flags & 1u) ? T.lim : lo, T.lim, tl);
-                            hr = slab(n.rmin, n.rmax, q_a, q_b, (flags & 2u) ? T.lim : lo, T.lim, tr);
-                            cl = n.left, cr = n.right;
+                            hl = slab_q(w0.x, w0.y, w0.z, sel_x, sel_y, sel_z, q_a, q_b, (flags & 1u) ? T.lim : lo, T.lim, tl);
+                            hr = slab_q(w0.w, w1.x, w1.y, sel_x, sel_y, sel_z, q_a, q_b, (flags & 2u) ? T.lim : lo, T.lim, tr);
+                            cl = (int)w1.z, cr = (int)w1.w;
                         } else {
                             const DBvhNode &n = s.bvh[ref];
                             hl = slab(n.lmin, n.lmax, q_a, q_b, (flags & 1u) ? T.lim : lo, T.lim, tl);
