@@ -725,7 +725,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     bool in_pass = false;
     int pos = 0, end = 0, sb = 0, cur = RTC_NO_NODE;
     V3 inv_d = mk(0., 0., 0.), oi = mk(0., 0., 0.);
-    int cache_id = -1;  // ancestor chain the cached ray is expressed in (GROUPS)
+    // The ray in group space is cached per lane across the leaves of a pass when primitives sit in groups.  The
+    // persistent schedule is chosen for glass-heavy scenes, where the 13 registers this costs between passes are
+    // worth more than the transform it saves: there the ray is transformed per grouped leaf.
+    constexpr bool RAY_CACHE = GROUPS && !PERSISTENT;
+    int cache_id = -1;  // ancestor chain the cached ray is expressed in
     Ray cache_ray = ray;
     // ---- shading context (valid from the closest hit until the last shadow ray of that hit) ----
     int h_prim = -1, h_mat = 0;  // hit primitive and its material index (read once per hit)
@@ -868,16 +872,17 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             // ---- (A) phase 1: lockstep walk over the always-tested list (i, L.* are wave-uniform) ----
             const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
             int u_cache = -1;
+            Ray u_ray = ray;  // lockstep list: the cache key is wave-uniform and lives only inside this loop
             for (int i = 0; i < n_lin; i++) {
                 const __attribute__((address_space(4))) DLeaf &L = lin[i];
                 Ray r = ray;
                 if (GROUPS && L.anc_len > 0) {
                     if (L.anc_id != u_cache) {
-                        cache_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
+                        u_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
                         u_cache = L.anc_id;
                         CNT(ST_XFORM, L.anc_len);  // Group::intersect transforms the ray once per group
                     }
-                    r = cache_ray;
+                    r = u_ray;
                 }
                 if (!(any_hit && T.prim >= 0)) {
                     CNT(ST_XFORM, L.type < PT_TRIANGLE ? 1 : 0);  // the shape's own Ray::transform
@@ -885,7 +890,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     isect_leaf(L, r, T);
                 }
             }
-            if (GROUPS) cache_id = u_cache;
+            if (RAY_CACHE) cache_ray = u_ray;
+            if (RAY_CACHE || STATS) cache_id = u_cache;
             if (use_bvh && s.n_bounded > 0 && !(any_hit && T.prim >= 0)) {
                 // ---- phase 2 set-up: ordered BVH traversal, leaves tested as they are reached ----
                 inv_d = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
@@ -976,12 +982,20 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         // group share it: the ray in group space is cached per lane.
                         Ray r = ray;
                         if (GROUPS && L.anc_len > 0) {
-                            if (L.anc_id != cache_id) {
-                                cache_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
-                                cache_id = L.anc_id;
-                                CNT(ST_XFORM, L.anc_len);
+                            if (!RAY_CACHE) {
+                                r = through_ancestors(s, L.anc_off, L.anc_len, ray);
+                                if (STATS && L.anc_id != cache_id) {  // counted as the reference does: once per group
+                                    CNT(ST_XFORM, L.anc_len);
+                                    cache_id = L.anc_id;
+                                }
+                            } else {
+                                if (L.anc_id != cache_id) {
+                                    cache_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
+                                    cache_id = L.anc_id;
+                                    CNT(ST_XFORM, L.anc_len);
+                                }
+                                r = cache_ray;
                             }
-                            r = cache_ray;
                         }
                         CNT(ST_XFORM, L.type < PT_TRIANGLE ? 1 : 0);
                         CNT(ST_PRIM0 + L.type, 1);
