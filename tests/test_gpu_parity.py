@@ -127,6 +127,21 @@ def test_stress_scene_full_size_bvh_equals_bruteforce():
     assert np.array_equal(a, c)  # persistent and static schedules agree bitwise
 
 
+def test_stress_scene_full_size_matches_oracle():
+    # the FULL 100k-sphere + teapot scene (quantised nodes, compact sphere leaves, persistent schedule) against the
+    # oracle's linear scan, at an image size and bounce budget the oracle finishes in seconds
+    world, cam = rtc.stress_scene.build(100_000, 32, 18)
+    scene = cam.compile(world, device=0)
+    try:
+        gpu = scene.render(depth=3)
+    finally:
+        scene.close()
+    ref = sf.to_oracle(world, cam).render(depth=3)
+    rep = sf.compare(gpu, ref)
+    print(f"[parity] stress 100k 32x18 depth 3: {rep}")
+    assert rep["nan"] == 0 and rep["max_8bit"] <= 1 and rep["max_abs"] < F64_TOL, rep
+
+
 def test_cpp_loader_render_equals_python_loader():
     import os
     path = os.path.join(sf.SCENES, "teapot.yaml")
