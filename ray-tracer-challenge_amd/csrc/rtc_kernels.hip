@@ -554,10 +554,16 @@ DEV unsigned canvas_row(const DRenderParams &p, unsigned l) {
     return (k * p.tile_count + p.tile_index) * p.tile_rows + (l - k * p.tile_rows);
 }
 
+// RTC_TIMING_ONLY (diagnostic build, tools/build_variant.sh): the counting kernel keeps only its per-stage clocks
+// (lane 0, one s_memtime per stage) so that the stage shares it reports are those of the plain kernel
+#ifdef RTC_TIMING_ONLY
+#define CNT(idx, n) do { } while (0)
+#else
 #define CNT(idx, n)                                   \
     do {                                              \
         if (STATS) cnt.c[idx] += (unsigned long long)(n); \
     } while (0)
+#endif
 
 // Ray::transform through a run of ancestor (group) inverses, root first (shape.rs:2035)
 DEV Ray through_ancestors(const DScene &s, int off, int len, Ray r) {
@@ -615,7 +621,7 @@ DEV V3 normal_at(const DScene &s, const DPrim &p, V3 world_point, double u, doub
         // normalisation remains
         n = normalize(n);
     } else {
-        const double *own = s.xforms[GROUPS ? s.chains[p.chain_off + p.chain_len - 1] : p.own_xform].inv;
+        const double *own = s.xforms[p.own_xform].inv;  // == the chain's last entry, without the look-up
         V3 lp = world_point;
         if (GROUPS)
             for (int k = 0; k < p.chain_len - 1; k++) lp = xf_point(s.xforms[s.chains[p.chain_off + k]].inv, lp);
@@ -1076,9 +1082,13 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             if (T.prim < 0 || s.n_lights == 0) {
                 next_ray = true;
             } else {
-                const DPrim &p = s.prims[T.prim];
+                // the whole primitive record is requested at once, and the one material field this block needs
+                // before the normal's own look-ups: three dependent round trips (record; transform + material;
+                // parents) instead of one per field
+                const DPrim p = s.prims[T.prim];
+                __builtin_amdgcn_sched_barrier(0);
                 h_mat = p.material;
-                const DMaterial &m = s.materials[h_mat];
+                const double m_transparency = s.materials[h_mat].transparency;
                 // Intersection::prepare_computations, intersection.rs:123-148
                 h_prim = T.prim;
                 const V3 h_point = ray.o + ray.d * T.lim;
@@ -1091,7 +1101,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 pk[PK_N1 * RTC_WAVE] = 1.;
                 pk[PK_N2 * RTC_WAVE] = 1.;
                 CNT(ST_SHADED, 1);
-                if (remaining > 0 && m.transparency != 0.) {
+                if (remaining > 0 && m_transparency != 0.) {
                     // containers loop (intersection.rs:150-179) in streaming form: second pass over the same
                     // ray with T.lim / T.prim (the hit) held fixed
                     T.a = 0., T.b = 0., T.c_best_prim = -1, T.c_hit_open = 0;

@@ -1,5 +1,6 @@
 import importlib, sys, time
 sys.path.insert(0, '.')
+import os
 rtc = importlib.import_module("ray-tracer-challenge_amd")
 n, w, h = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 t = time.time(); world, cam = rtc.stress_scene.build(n, w, h); print("build %.1fs" % (time.time() - t), flush=True)
