@@ -1077,6 +1077,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         // state machine
         // =====================================================================================
         bool begin_lights = false, finish = false, next_ray = false, need_shadow = false;
+        double f_refl = 0., f_transp = 0.;  // the hit material's reflectivity / transparency when `finish` is set
         if (T.mode == MODE_CLOSEST) {
             // World::color_at, world.rs:30-38
             if (T.prim < 0 || s.n_lights == 0) {
@@ -1136,27 +1137,33 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             const bool shadowed =
                 T.prim >= 0 && (s.all_cast_shadow || s.materials[s.prims[T.prim].material].casts_shadow != 0);
             const DLight &lt = s.lights[li];
+            // everything this block and shade_hit's tail will read of the light and the material is requested here
+            // in one go (one round trip; as separate look-ups behind each branch it was five)
+            const DMaterial m = s.materials[h_mat];
+            const int lt_area = lt.is_area;
+            const unsigned lt_usteps = lt.usteps, lt_vsteps = lt.vsteps, lt_samples = lt.samples;
+            const V3 lt_pos = ld3(lt.position), lt_int = ld3(lt.intensity);
+            __builtin_amdgcn_sched_barrier(0);
             bool have = true;
             double inten;
-            if (lt.is_area) {  // light.rs:112-125: total += 1.0 per unshadowed sample, then total / samples
+            if (lt_area) {  // light.rs:112-125: total += 1.0 per unshadowed sample, then total / samples
                 if (!shadowed) unshadowed++;
                 su++;
-                if (su >= lt.usteps) su = 0, sv++;
-                if (sv < lt.vsteps) {
+                if (su >= lt_usteps) su = 0, sv++;
+                if (sv < lt_vsteps) {
                     have = false;
                     need_shadow = true;
                 }
-                inten = (double)unshadowed / (double)lt.samples;
+                inten = (double)unshadowed / (double)lt_samples;
             } else {  // light.rs:50-56
                 inten = shadowed ? 0. : 1.;
             }
             if (have) {
-                const DMaterial &m = s.materials[h_mat];
                 const V3 over = ray.o;  // the shadow ray starts at over_point (world.rs:50, 79)
                 V3 col = ld3(m.color);
                 if (PATTERNS && m.pattern >= 0) col = pattern_at_shape(s, m.pattern, s.prims[h_prim], over);
-                const V3 lightv = lt.is_area ? normalize(ld3(lt.position) - over) : ray.d;
-                const V3 c = lighting(m, col, lightv, ld3(lt.intensity), unpark3(pk, PK_EYE), unpark3(pk, PK_NORMAL), inten);
+                const V3 lightv = lt_area ? normalize(lt_pos - over) : ray.d;
+                const V3 c = lighting(m, col, lightv, lt_int, unpark3(pk, PK_EYE), unpark3(pk, PK_NORMAL), inten);
                 CNT(ST_LIGHT, 1);
                 park3(pk, PK_SURFACE, (li == 0) ? c : unpark3(pk, PK_SURFACE) + c);  // world.rs:70 left fold
                 li++;
@@ -1165,7 +1172,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 if (li < s.n_lights)
                     need_shadow = true;
                 else
-                    finish = true;
+                    finish = true, f_refl = m.reflectivity, f_transp = m.transparency;
             }
         }
         if (begin_lights) {
@@ -1175,20 +1182,19 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         if (finish) {
             // World::shade_hit (world.rs:42-76).  The reference evaluates reflected_color/refracted_color inside
             // the per-light loop (Q3), i.e. adds them n_lights times: that factor goes into the child's weight.
-            const DMaterial &m = s.materials[h_mat];
             const double w = pk[PK_W * RTC_WAVE];
             park3(pk, PK_COLOR, unpark3(pk, PK_COLOR) + unpark3(pk, PK_SURFACE) * w);
             next_ray = true;
             if (remaining > 0) {
-                const bool refl = m.reflectivity != 0.;
-                const bool refr = m.transparency != 0.;
+                const bool refl = f_refl != 0.;
+                const bool refr = f_transp != 0.;
                 if (refl || refr) {
                     // the parked context is read where it is used (volatile: one LDS read per use) so that
                     // nothing of it is held in registers -- or spilled to scratch -- across the square roots
                     const V3 h_normal = unpark3(pk, PK_NORMAL);
                     const V3 h_eye = unpark3(pk, PK_EYE);
                     double kr = 1., kt = 1.;
-                    if (m.reflectivity > 0. && m.transparency > 0.) {
+                    if (f_refl > 0. && f_transp > 0.) {
                         const double r = schlick(pk[PK_N1 * RTC_WAVE], pk[PK_N2 * RTC_WAVE], h_eye, h_normal);
                         CNT(ST_SCHLICK, 1);
                         kr = r;
@@ -1208,7 +1214,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                                 Pending &q = pend[sp];
                                 q.o = unpark3(pk, PK_POINT) - h_normal * RTC_EPS;  // under_point
                                 q.d = h_normal * (n_ratio * cos_i - cos_t) - h_eye * n_ratio;
-                                q.w = w * (nl * (m.transparency * kt));
+                                q.w = w * (nl * (f_transp * kt));
                                 q.remaining = remaining;  // Q2: not decremented (world.rs:142)
                                 if (STATS) pend_mult[sp] = mult * nl;
                                 refracted = true;
@@ -1223,7 +1229,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         // reflected_color, world.rs:93-106
                         ray.o = unpark3(pk, PK_POINT) + h_normal * RTC_EPS;  // over_point
                         ray.d = reflect(-h_eye, h_normal);
-                        pk[PK_W * RTC_WAVE] = w * (nl * (m.reflectivity * kr));
+                        pk[PK_W * RTC_WAVE] = w * (nl * (f_refl * kr));
                         remaining -= 1;
                     } else if (refracted) {
                         // the only child: it is the next ray
