@@ -812,6 +812,24 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             stamp = now__;                                               \
         }                                                                \
     } while (0)
+    // RTC_TIMING_ONLY builds also split the state machine's clock by block; the (otherwise unused) ray counters
+    // carry the result: primary = closest-hit block, container = containers block, shadow = light block,
+    // secondary = shade_hit tail, box = next-ray / shadow set-up
+#ifdef RTC_TIMING_ONLY
+    unsigned long long sub_stamp = 0;
+#define SUB_BEGIN() do { if (STATS) sub_stamp = __builtin_amdgcn_s_memtime(); } while (0)
+#define SUB_END(idx)                                                         \
+    do {                                                                     \
+        if (STATS) {                                                         \
+            const unsigned long long now__ = __builtin_amdgcn_s_memtime();   \
+            WCNT(idx, now__ - sub_stamp);                                    \
+            sub_stamp = now__;                                               \
+        }                                                                    \
+    } while (0)
+#else
+#define SUB_BEGIN() do { } while (0)
+#define SUB_END(idx) do { } while (0)
+#endif
     for (;;) {
         // =====================================================================================
         // refill: free lanes take the next pixels (wave-uniform control flow)
@@ -1078,6 +1096,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         // =====================================================================================
         bool begin_lights = false, finish = false, next_ray = false, need_shadow = false;
         double f_refl = 0., f_transp = 0.;  // the hit material's reflectivity / transparency when `finish` is set
+        SUB_BEGIN();
         if (T.mode == MODE_CLOSEST) {
             // World::color_at, world.rs:30-38
             if (T.prim < 0 || s.n_lights == 0) {
@@ -1112,6 +1131,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 }
                 begin_lights = true;
             }
+        }
+        SUB_END(ST_PRIMARY);
+        if (T.mode == MODE_CLOSEST) {
         } else if (T.mode == MODE_CONTAINER) {
             const double ri_hit = s.materials[h_mat].refractive_index;
             const double ri_other =
@@ -1131,6 +1153,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             pk[PK_N1 * RTC_WAVE] = n1;
             pk[PK_N2 * RTC_WAVE] = n2;
             begin_lights = true;
+        }
+        SUB_END(ST_CONTAINER);
+        if (T.mode != MODE_SHADOW) {
         } else {
             // World::is_shadowed (world.rs:78-91): only the NEAREST positive hit is consulted (Q5); when every
             // material casts shadows that equals "some hit has 0 < t < distance" (any-hit early exit).
@@ -1158,6 +1183,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             } else {  // light.rs:50-56
                 inten = shadowed ? 0. : 1.;
             }
+            SUB_END(ST_PRIM0 + 0);  // (timing build: look-ups of the light block)
             if (have) {
                 const V3 over = ray.o;  // the shadow ray starts at over_point (world.rs:50, 79)
                 V3 col = ld3(m.color);
@@ -1165,6 +1191,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 const V3 lightv = lt_area ? normalize(lt_pos - over) : ray.d;
                 const V3 c = lighting(m, col, lightv, lt_int, unpark3(pk, PK_EYE), unpark3(pk, PK_NORMAL), inten);
                 CNT(ST_LIGHT, 1);
+                SUB_END(ST_PRIM0 + 1);  // (timing build: Material::lighting)
                 park3(pk, PK_SURFACE, (li == 0) ? c : unpark3(pk, PK_SURFACE) + c);  // world.rs:70 left fold
                 li++;
                 su = sv = 0;
@@ -1175,6 +1202,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     finish = true, f_refl = m.reflectivity, f_transp = m.transparency;
             }
         }
+        SUB_END(ST_SHADOW);
         if (begin_lights) {
             li = 0, su = sv = 0, unshadowed = 0;
             need_shadow = true;
@@ -1249,6 +1277,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 }
             }
         }
+        SUB_END(ST_SECONDARY);
         if (next_ray) {
             if (sp == 0) {
                 alive = false;
@@ -1284,6 +1313,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             park3(pk, PK_COLOR, mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.));
             alive = false;
         }
+        SUB_END(ST_BOX);
         if (PERSISTENT && !alive) write_pixel();  // the lane is free for the next pixel
         }  // if (alive)
         STAGE_END(ST_CYC_SHADE);

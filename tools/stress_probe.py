@@ -19,5 +19,9 @@ for mode in sys.argv[4:]:
         if d and sum(d):
             tot = float(sum(d[:4])) or 1.0
             print("  stage cycles (share): refill %.3f start %.3f traverse %.3f shade %.3f" % tuple(x / tot for x in d[:4]))
+            st = sc.last_stats
+            sub = [st.get("primary_rays", 0), st.get("container_passes", 0), st.get("shadow_rays", 0), st.get("secondary_rays", 0), st.get("box_tests", 0)]
+            if os.environ.get("RTC_AMD_LIB", "").endswith("timing.so") and sum(sub):
+                print("  state machine sub-blocks (share of shade): closest %.3f containers %.3f lights %.3f shade_hit tail %.3f next ray %.3f" % tuple(x / float(sum(sub)) for x in sub))
             for name, r, l in (("start", d[4], d[5]), ("traverse", d[6], d[7]), ("shade", d[8], d[9])):
                 print("  %-9s rounds %d  lanes/round %.1f" % (name, r, l / max(r, 1)))
