@@ -977,6 +977,16 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     const unsigned n_leaf = (unsigned)__popcll(__ballot(at_leaf));
                     const unsigned n_node = (unsigned)__popcll(__ballot(!at_leaf));
                     if (at_leaf && n_node != 0u && n_leaf * prm.leaf_den < n_leaf + n_node) continue;
+#ifdef RTC_TIMING_ONLY
+                    if (STATS) {  // lane participation of the two halves of a step (ballots: the lanes still here)
+                        const unsigned long long lm = __ballot(at_leaf), nm = __ballot(!at_leaf);
+                        const unsigned first = (unsigned)__ffsll((long long)(lm | nm)) - 1u;
+                        if (lane == first) {
+                            if (nm) cnt.c[ST_PRIM0 + 2] += 1, cnt.c[ST_PRIM0 + 3] += __popcll(nm);
+                            if (lm) cnt.c[ST_PRIM0 + 4] += 1, cnt.c[ST_PRIM0 + 5] += __popcll(lm);
+                        }
+                    }
+#endif
                     if (at_leaf && QNODES && (pos & RTC_LEAF_COMPACT)) {
                         // sphere with a diagonal + translation inverse: 64-byte record, the off-diagonal zeros are
                         // rebuilt with their signs and the arithmetic is the general sphere's (same bits)

@@ -23,5 +23,8 @@ for mode in sys.argv[4:]:
             sub = [st.get("primary_rays", 0), st.get("container_passes", 0), st.get("shadow_rays", 0), st.get("secondary_rays", 0), st.get("box_tests", 0)]
             if os.environ.get("RTC_AMD_LIB", "").endswith("timing.so") and sum(sub):
                 print("  state machine sub-blocks (share of shade): closest %.3f containers %.3f lights %.3f shade_hit tail %.3f next ray %.3f" % tuple(x / float(sum(sub)) for x in sub))
+            pt = st.get("prim_tests")
+            if os.environ.get("RTC_AMD_LIB", "").endswith("timing.so") and pt[2]:
+                print("  step halves: node half ran %d times with %.1f lanes, leaf half %d times with %.1f lanes" % (pt[2], pt[3] / max(pt[2], 1), pt[4], pt[5] / max(pt[4], 1)))
             for name, r, l in (("start", d[4], d[5]), ("traverse", d[6], d[7]), ("shade", d[8], d[9])):
                 print("  %-9s rounds %d  lanes/round %.1f" % (name, r, l / max(r, 1)))
