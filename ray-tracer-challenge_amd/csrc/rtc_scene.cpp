@@ -360,8 +360,17 @@ struct Builder {
     std::vector<BuildNode> nodes;
     bool median_only;
     uint32_t max_depth = 0;
-    static constexpr int MAX_LEAF = 4;
-    static constexpr int BINS = 16;
+#ifndef RTC_BVH_MAX_LEAF
+#define RTC_BVH_MAX_LEAF 4
+#endif
+#ifndef RTC_BVH_BINS
+#define RTC_BVH_BINS 16
+#endif
+#ifndef RTC_BVH_TRAV_COST
+#define RTC_BVH_TRAV_COST 0.5
+#endif
+    static constexpr int MAX_LEAF = RTC_BVH_MAX_LEAF;
+    static constexpr int BINS = RTC_BVH_BINS;
 
     static double area(const Bounds &b) {
         const double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
@@ -440,7 +449,7 @@ struct Builder {
             }
             const double leaf_cost = area(nodes[idx].b) * count;
             // traversal step ~ 1/2 primitive test (f64 slab test vs transform + quadratic / Moeller-Trumbore)
-            if (best_axis >= 0 && (count > MAX_LEAF || best_cost + 0.5 * area(nodes[idx].b) < leaf_cost)) {
+            if (best_axis >= 0 && (count > MAX_LEAF || best_cost + RTC_BVH_TRAV_COST * area(nodes[idx].b) < leaf_cost)) {
                 const double ext = cb.hi[best_axis] - cb.lo[best_axis];
                 const double scale = BINS / ext;
                 const double lo = cb.lo[best_axis];
