@@ -1340,11 +1340,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
 }
 
 template <class K>
-static unsigned resident_waves(K kernel, unsigned n_cu) {
+static unsigned resident_waves_per_cu(K kernel) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RTC_WAVE, 0) != hipSuccess || per_cu <= 0)
         per_cu = 4 * RTC_MIN_WAVES;
-    return n_cu * (unsigned)per_cu;
+    return (unsigned)per_cu;
 }
 
 template <bool STATS, bool GROUPS, bool PATTERNS, bool QNODES>
@@ -1359,8 +1359,9 @@ static void launch_variant(const DScene &scene, DRenderParams &params, double *d
     // tile finish together); persistent = resident waves draw tiles from the counters and refill free lanes
     // (best when some pixels grow ray trees thousands of rays deep)
     if (params.persistent) {
-        static unsigned cap = 0;
-        if (!cap) cap = resident_waves(k_render<STATS, GROUPS, PATTERNS, true, QNODES>, n_cu);
+        // occupancy is a property of the code object (queried once per variant); the CU count is this device's
+        static const unsigned per_cu = resident_waves_per_cu(k_render<STATS, GROUPS, PATTERNS, true, QNODES>);
+        const unsigned cap = per_cu * n_cu;
         const unsigned waves = tiles < cap ? tiles : cap;
         static const unsigned refill_env = getenv("RTC_REFILL_MIN") ? (unsigned)atoi(getenv("RTC_REFILL_MIN")) : 0u;
         params.refill_min = refill_env ? refill_env : RTC_REFILL_MIN;
