@@ -183,12 +183,13 @@ def main():
         kernel_ms_max = kernel_ms
 
     if distributed and args.rehearse_on_one_gpu and rank == 0:
-        # the assembled canvas must equal a one-rank render of the whole frame, bit for bit
+        # the assembled canvas must equal a one-rank render of the whole frame (bit for bit except where the persistent
+        # schedule split a pixel's ray tree between lanes and added the parts: a few f64 additions in another order)
         full = torch.zeros((vsize, hsize, 3), dtype=torch.float64, device=dev)
         kw = {k: v for k, v in ropts.items() if not k.startswith("tile_")}
         scene.render_device(full.data_ptr(), stream.cuda_stream, **kw)
         torch.cuda.synchronize(dev)
-        assert torch.equal(full, canvas_ext[:vsize]), "gathered canvas differs from the single-rank frame"
+        assert float((full - canvas_ext[:vsize]).abs().max()) < 1e-12, "gathered canvas differs from the single-rank frame"
         print("[rehearsal] gathered canvas == single-rank frame", file=sys.stderr)
     if rank != 0:
         if distributed:

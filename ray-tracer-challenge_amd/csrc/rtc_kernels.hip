@@ -34,7 +34,9 @@ namespace rtc {
 #define RTC_WAVE 64
 #define RTC_BVH_STACK 32
 #define RTC_MAX_DEPTH_STACK 8
+#ifndef RTC_MAX_RAYS_PER_PIXEL
 #define RTC_MAX_RAYS_PER_PIXEL 65536
+#endif
 #define RTC_NO_NODE ((int)0x80000000)  // "no node in hand": the next step pops the stack
 #ifndef RTC_STEPS_PER_CHECK
 #define RTC_STEPS_PER_CHECK 8         // traversal steps between two looks at the wave's occupancy
@@ -668,6 +670,14 @@ DEV V3 normal_at(const DScene &s, const DPrim &p, V3 world_point, double u, doub
     return n;
 }
 
+// value of lane `src` (wave-uniform index) for every lane
+DEV unsigned lane_u32(unsigned v, int src) { return (unsigned)__builtin_amdgcn_readlane((int)v, src); }
+DEV double lane_f64(double v, int src) {
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 // The megakernel.  Per lane it is a small state machine around ONE intersection pass:
 //   MODE_CLOSEST   World::color_at's closest hit for a primary / reflect / refract ray
 //   MODE_CONTAINER second pass over the same ray for n1/n2 (only for transparent hits)
@@ -695,6 +705,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     const unsigned n_tiles = prm.tiles_x * prm.tiles_y;
 
+#ifdef RTC_TIMING_ONLY
+    const unsigned long long wave_start_rt = __builtin_amdgcn_s_memrealtime();
+#endif
     Counters cnt;
     if (STATS)
         for (int i = 0; i < ST_COUNT; i++) cnt.c[i] = 0;
@@ -714,9 +727,13 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     // ---- path state ----
     double mult = 1.;  // STATS only: how many times the reference traces this ray (Q3)
     int remaining = 0;
+    // waiting refracted rays: a ring (first entry at pbase) so that the OLDEST one -- the root of the largest subtree
+    // still to be traced -- can be handed to a free lane at the end of the frame (see "tail" below)
     Pending pend[RTC_MAX_DEPTH_STACK];
     double pend_mult[STATS ? RTC_MAX_DEPTH_STACK : 1];  // STATS only: `mult` of the waiting rays
-    int sp = 0;
+    int sp = 0, pbase = 0;
+    bool shared = false;  // this lane's pixel is being traced by more than one lane: results are ADDED to the canvas
+#define RTC_PEND(i) (((i) + pbase) & (RTC_MAX_DEPTH_STACK - 1))
     int rays = 0;
     const double nl = (double)s.n_lights;
     // ---- current ray ----
@@ -750,7 +767,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
 
     // binds this lane to pixel `pix`: primary ray and a fresh path state, or a black pixel (Q1 / tile padding)
     auto init_pixel = [&]() {
-        const unsigned tile = pix >> 6, q = pix & 63u;
+        const unsigned tile = prm.tile_order ? n_tiles - 1u - (pix >> 6) : (pix >> 6), q = pix & 63u;
         const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
         const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
         const unsigned y = canvas_row(prm, l);
@@ -769,7 +786,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 pk[PK_W * RTC_WAVE] = 1.;
                 mult = 1.;
                 remaining = (int)prm.depth;
-                sp = 0;
+                sp = 0, pbase = 0;
+                shared = false;
                 rays = 1;
                 T.mode = MODE_CLOSEST;
                 T.lim = inf, T.prim = -1;
@@ -783,12 +801,27 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     };
     // the pixel is finished: Canvas::write_pixel (camera.rs:87-91)
     auto write_pixel = [&]() {
-        const unsigned tile = pix >> 6, q = pix & 63u;
+        const unsigned tile = prm.tile_order ? n_tiles - 1u - (pix >> 6) : (pix >> 6), q = pix & 63u;
         const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
         const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
         const V3 color = unpark3(pk, PK_COLOR);
         double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
-        px[0] = color.x, px[1] = color.y, px[2] = color.z;
+        if (PERSISTENT && shared) {
+            // one of several lanes that traced parts of this pixel's ray tree (the pixel was zeroed when the first
+            // part was handed over): the order of these few additions is the only run-to-run freedom of a frame
+            atomicAdd(px + 0, color.x), atomicAdd(px + 1, color.y), atomicAdd(px + 2, color.z);
+        } else {
+            px[0] = color.x, px[1] = color.y, px[2] = color.z;
+        }
+    };
+    // tail only: the pixel of this lane is about to be shared -- its canvas entry becomes an accumulator
+    auto zero_pixel = [&]() {
+        const unsigned tile = prm.tile_order ? n_tiles - 1u - (pix >> 6) : (pix >> 6), q = pix & 63u;
+        const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
+        const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
+        double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
+        px[0] = 0., px[1] = 0., px[2] = 0.;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the stores are in L2 before any lane adds to them)
     };
     bool rendered = false;
     if (!PERSISTENT) {
@@ -875,6 +908,52 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     r_next += taken < avail ? taken : avail;
                 }
             }
+            // ---- tail: no tile is left.  A few pixels of the stress scene grow ray trees of 10^4 rays, which one lane
+            // traces in ~0.3 s -- a sixth of the whole frame -- while its neighbours sit idle.  Free lanes therefore take
+            // over the oldest waiting ray (the largest untraced subtree) of a busy lane of the same wave. ----
+            if (PERSISTENT && exhausted && r_next == r_end) {
+                unsigned long long recv = __ballot(!alive);
+                unsigned long long don = __ballot(alive && sp > 0);
+                while (recv != 0ull && don != 0ull) {
+                    const int dl = __ffsll((long long)don) - 1, rl = __ffsll((long long)recv) - 1;  // wave-uniform
+                    don &= don - 1ull, recv &= recv - 1ull;
+                    Pending q;
+                    q.o = q.d = mk(0., 0., 0.), q.w = 0., q.remaining = 0;
+                    double qm = 0.;
+                    if ((int)lane == dl) {
+                        q = pend[pbase];
+                        if (STATS) qm = pend_mult[pbase];
+                        pbase = (pbase + 1) & (RTC_MAX_DEPTH_STACK - 1);
+                        sp--;
+                        if (!shared) {
+                            zero_pixel();
+                            shared = true;
+                        }
+                    }
+                    const unsigned qpix = lane_u32(pix, dl);
+                    const int qrem = (int)lane_u32((unsigned)q.remaining, dl);
+                    const V3 qo = mk(lane_f64(q.o.x, dl), lane_f64(q.o.y, dl), lane_f64(q.o.z, dl));
+                    const V3 qd = mk(lane_f64(q.d.x, dl), lane_f64(q.d.y, dl), lane_f64(q.d.z, dl));
+                    const double qw = lane_f64(q.w, dl);
+                    const double qmult = STATS ? lane_f64(qm, dl) : 0.;
+                    if ((int)lane == rl) {
+                        pix = qpix;
+                        shared = true;
+                        alive = true;
+                        ray.o = qo, ray.d = qd, remaining = qrem;
+                        park3(pk, PK_COLOR, mk(0., 0., 0.));
+                        pk[PK_W * RTC_WAVE] = qw;
+                        if (STATS) mult = qmult;
+                        sp = 0, pbase = 0;
+                        rays = 1;
+                        in_pass = false;
+                        T.mode = MODE_CLOSEST;
+                        T.lim = inf, T.prim = -1;
+                        CNT(ST_SECONDARY, 1);
+                        CNT(ST_SECONDARY_REF, mult);
+                    }
+                }
+            }
             if (__ballot(alive) == 0ull) break;  // no pixel in flight and none left: the wave is done
         }
         STAGE_END(ST_CYC_REFILL);
@@ -942,7 +1021,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 // and a pixel is available): the state machine then runs for a batch of lanes, not for each one
                 unsigned long long idle = __ballot(alive && !in_pass);
                 const unsigned long long dead = __ballot(!alive);
-                if (!(exhausted && r_next == r_end) && (unsigned)__popcll(dead) >= prm.refill_min) idle |= dead;
+                if (!(exhausted && r_next == r_end)) {
+                    if ((unsigned)__popcll(dead) >= prm.refill_min) idle |= dead;
+                } else if (__ballot(alive && sp > 0) != 0ull) {
+                    idle |= dead;  // tail: they can take over a waiting ray
+                }
                 if ((unsigned)__popcll(idle) >= prm.stay_min) break;
             }
             if (alive && in_pass) {
@@ -1249,12 +1332,12 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                             if (sp < RTC_MAX_DEPTH_STACK) {
                                 // written straight into its stack slot: nothing of it is held across the reflection
                                 const double cos_t = sqrt(1. - sin2_t);
-                                Pending &q = pend[sp];
+                                Pending &q = pend[RTC_PEND(sp)];
                                 q.o = unpark3(pk, PK_POINT) - h_normal * RTC_EPS;  // under_point
                                 q.d = h_normal * (n_ratio * cos_i - cos_t) - h_eye * n_ratio;
                                 q.w = w * (nl * (f_transp * kt));
                                 q.remaining = remaining;  // Q2: not decremented (world.rs:142)
-                                if (STATS) pend_mult[sp] = mult * nl;
+                                if (STATS) pend_mult[RTC_PEND(sp)] = mult * nl;
                                 refracted = true;
                             } else {
                                 CNT(ST_OVERFLOW, 1);
@@ -1271,7 +1354,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         remaining -= 1;
                     } else if (refracted) {
                         // the only child: it is the next ray
-                        const Pending &q = pend[sp];
+                        const Pending &q = pend[RTC_PEND(sp)];
                         ray.o = q.o, ray.d = q.d;
                         pk[PK_W * RTC_WAVE] = q.w;
                     }
@@ -1293,10 +1376,10 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 alive = false;
             } else {
                 sp--;
-                const Pending q = pend[sp];
+                const Pending q = pend[RTC_PEND(sp)];
                 ray.o = q.o, ray.d = q.d, remaining = q.remaining;
                 pk[PK_W * RTC_WAVE] = q.w;
-                if (STATS) mult = pend_mult[sp];
+                if (STATS) mult = pend_mult[RTC_PEND(sp)];
                 T.mode = MODE_CLOSEST;
                 T.lim = inf, T.prim = -1;
                 CNT(ST_SECONDARY, 1);
@@ -1330,6 +1413,15 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     }
     if (!PERSISTENT && rendered) write_pixel();  // the whole tile at once
 
+#ifdef RTC_TIMING_ONLY
+    if (STATS && lane == 0) {
+        // wave lifetimes on the constant 100 MHz clock: sum of lifetimes, latest end, earliest start (as max of ~start)
+        const unsigned long long end_rt = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&stats[ST_PRIM0 + 6], end_rt - wave_start_rt);
+        atomicMax(&stats[ST_SHADED], end_rt);
+        atomicMax(&stats[ST_LIGHT], ~wave_start_rt);
+    }
+#endif
     if (STATS) {
         for (int i = 0; i < ST_COUNT; i++) {
             unsigned long long v = cnt.c[i];
@@ -1351,6 +1443,8 @@ template <bool STATS, bool GROUPS, bool PATTERNS, bool QNODES>
 static void launch_variant(const DScene &scene, DRenderParams &params, double *d_rgb, unsigned long long *ds,
                            unsigned *d_work, unsigned n_cu, hipStream_t st) {
     const unsigned tiles = params.tiles_x * params.tiles_y;
+    static const unsigned order_env = getenv("RTC_TILE_ORDER") ? (unsigned)atoi(getenv("RTC_TILE_ORDER")) : 0u;
+    params.tile_order = order_env;
     static const unsigned leaf_env = getenv("RTC_LEAF_DEN") ? (unsigned)atoi(getenv("RTC_LEAF_DEN")) : 0u;
     // large hierarchies (quantised nodes) are latency bound: there a primitive test waits until a third of the
     // traversing lanes want one (stress 4K 2.86 -> 2.61 s); on small scenes waiting buys nothing

@@ -178,6 +178,7 @@ struct DRenderParams {
     uint32_t dyn_base;          // first tile handed out through the device-wide counters (= grid size)
     uint32_t stay_min;          // waiting lanes at which a wave leaves the traversal loop to serve them (persistent)
     uint32_t refill_min;        // free lanes a wave waits for before it assigns new pixels (1..64)
+    uint32_t tile_order;        // 0: tiles are handed out top row first, 1: bottom row first
     uint32_t leaf_den;          // primitive tests run when at least 1/leaf_den of the traversing lanes wait at a leaf
 };
 

@@ -110,7 +110,7 @@ def test_stress_scene_small_matches_oracle():
 
 def test_stress_scene_full_size_bvh_equals_bruteforce():
     # size-independent property on the FULL 100k-sphere + teapot scene: the BVH must return exactly what the
-    # reference's linear scan returns -- compared bitwise on one 8-row tile.  (The image is small and the bounce
+    # reference's linear scan returns -- compared on one 8-row tile (bitwise under the static schedule).  (The image is small and the bounce
     # budget 2 so that the brute-force side, 106k primitive tests per ray, stays within seconds.)
     world, cam = rtc.stress_scene.build(100_000, 480, 270)
     scene = cam.compile(world, device=0)
@@ -120,11 +120,17 @@ def test_stress_scene_full_size_bvh_equals_bruteforce():
         a = scene.render(use_bvh=1, **kw)
         b = scene.render(use_bvh=2, **kw)
         c = scene.render(use_bvh=1, schedule=1, **kw)
+        scene_static_bvh_vs_brute = (c, scene.render(use_bvh=2, schedule=1, **kw))
     finally:
         scene.close()
     assert np.abs(a).sum() > 0
-    assert np.array_equal(a, b)
-    assert np.array_equal(a, c)  # persistent and static schedules agree bitwise
+    # The static schedule (one workgroup per tile) is bit-reproducible.  The persistent one hands waiting rays of the
+    # last, heaviest pixels to free lanes at the end of a frame and ADDS the parts: the order of those few f64
+    # additions is timing dependent (observed <= 1e-15), everything else is identical arithmetic.
+    assert float(np.max(np.abs(a - b))) < 1e-12
+    assert float(np.max(np.abs(a - c))) < 1e-12
+    d = scene_static_bvh_vs_brute
+    assert np.array_equal(d[0], d[1])  # BVH == linear scan, bit for bit (static schedule)
 
 
 def test_stress_scene_full_size_matches_oracle():

@@ -26,5 +26,8 @@ for mode in sys.argv[4:]:
             pt = st.get("prim_tests")
             if os.environ.get("RTC_AMD_LIB", "").endswith("timing.so") and pt[2]:
                 print("  step halves: node half ran %d times with %.1f lanes, leaf half %d times with %.1f lanes" % (pt[2], pt[3] / max(pt[2], 1), pt[4], pt[5] / max(pt[4], 1)))
+            if os.environ.get("RTC_AMD_LIB", "").endswith("timing.so") and st.get("shaded_hits"):
+                span = st["shaded_hits"] - ((~st["light_evals"]) & 0xFFFFFFFFFFFFFFFF)
+                print("  wave lifetimes (100 MHz ticks): kernel span %d, mean wave lifetime %.0f = %.3f of the span" % (span, pt[6] / 3072.0, pt[6] / 3072.0 / max(span, 1)))
             for name, r, l in (("start", d[4], d[5]), ("traverse", d[6], d[7]), ("shade", d[8], d[9])):
                 print("  %-9s rounds %d  lanes/round %.1f" % (name, r, l / max(r, 1)))
