@@ -670,6 +670,22 @@ DEV V3 normal_at(const DScene &s, const DPrim &p, V3 world_point, double u, doub
     return n;
 }
 
+// device-scope accesses to the work buffer (coherent between the XCDs' L2s)
+DEV unsigned wb_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void wb_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV bool wb_cas(unsigned *p, unsigned expect, unsigned desired) {
+    return __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+}
+DEV void wb_store64(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEV unsigned long long wb_load64(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEV unsigned long long f64_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+DEV double bits_f64(unsigned long long v) { return __longlong_as_double((long long)v); }
+
 // value of lane `src` (wave-uniform index) for every lane
 DEV unsigned lane_u32(unsigned v, int src) { return (unsigned)__builtin_amdgcn_readlane((int)v, src); }
 DEV double lane_f64(double v, int src) {
@@ -814,6 +830,24 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             px[0] = color.x, px[1] = color.y, px[2] = color.z;
         }
     };
+    // a free lane takes over a waiting ray of another lane (of this wave or of another one): it traces that subtree
+    // of the pixel's ray tree and adds its part to the canvas
+    auto adopt = [&](unsigned qpix, V3 qo, V3 qd, double qw, double qmult, int qrem) {
+        pix = qpix;
+        shared = true;
+        alive = true;
+        ray.o = qo, ray.d = qd, remaining = qrem;
+        park3(pk, PK_COLOR, mk(0., 0., 0.));
+        pk[PK_W * RTC_WAVE] = qw;
+        if (STATS) mult = qmult;
+        sp = 0, pbase = 0;
+        rays = 1;
+        in_pass = false;
+        T.mode = MODE_CLOSEST;
+        T.lim = inf, T.prim = -1;
+        CNT(ST_SECONDARY, 1);
+        CNT(ST_SECONDARY_REF, mult);
+    };
     // tail only: the pixel of this lane is about to be shared -- its canvas entry becomes an accumulator
     auto zero_pixel = [&]() {
         const unsigned tile = prm.tile_order ? n_tiles - 1u - (pix >> 6) : (pix >> 6), q = pix & 63u;
@@ -823,6 +857,10 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         px[0] = 0., px[1] = 0., px[2] = 0.;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the stores are in L2 before any lane adds to them)
     };
+    if (PERSISTENT && prm.share && lane == 0) atomicAdd(work + RTC_WORK_BUSY, 1u);
+    unsigned long long *const my_box =
+        (unsigned long long *)((char *)work + RTC_WORK_MBOX_BYTES) + (size_t)blockIdx.x * 64u * RTC_MBOX_ITEM_U64;
+    unsigned share_round = 0;  // wave-uniform: varies the waves probed for hunger
     bool rendered = false;
     if (!PERSISTENT) {
         // static schedule: workgroup b renders tile b and nothing else
@@ -936,25 +974,106 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     const V3 qd = mk(lane_f64(q.d.x, dl), lane_f64(q.d.y, dl), lane_f64(q.d.z, dl));
                     const double qw = lane_f64(q.w, dl);
                     const double qmult = STATS ? lane_f64(qm, dl) : 0.;
-                    if ((int)lane == rl) {
-                        pix = qpix;
-                        shared = true;
-                        alive = true;
-                        ray.o = qo, ray.d = qd, remaining = qrem;
-                        park3(pk, PK_COLOR, mk(0., 0., 0.));
-                        pk[PK_W * RTC_WAVE] = qw;
-                        if (STATS) mult = qmult;
-                        sp = 0, pbase = 0;
-                        rays = 1;
-                        in_pass = false;
-                        T.mode = MODE_CLOSEST;
-                        T.lim = inf, T.prim = -1;
-                        CNT(ST_SECONDARY, 1);
-                        CNT(ST_SECONDARY_REF, mult);
+                    if ((int)lane == rl) adopt(qpix, qo, qd, qw, qmult, qrem);
+                }
+                // ---- and the waves that ran out of rays altogether take over waiting rays of other WAVES: a wave
+                // without work publishes its hunger, a wave with waiting rays claims one hungry wave per round
+                // (compare-and-swap on that wave's mailbox state) and moves its lanes' oldest waiting rays there. ----
+                const unsigned long long don2 = __ballot(alive && sp > 0);
+                if (prm.share && don2 != 0ull) {
+                    int target = -1;
+                    if (lane == 0 && wb_load(work + RTC_WORK_HUNGRY) != 0u) {
+                        const unsigned ht = wb_load(work + RTC_WORK_HINT_TAIL);
+                        for (unsigned k = 0; k < 6u && target < 0; k++) {
+                            unsigned cand;
+                            if (k < 4u) {  // the most recent hints first
+                                if (ht <= k) continue;
+                                cand = wb_load(work + RTC_WORK_HINTS + ((ht - 1u - k) & 255u));
+                            } else {  // hints are a ring of 256: older hungry waves are found by chance
+                                cand = (blockIdx.x * 2654435761u + share_round * 40503u + k) % prm.n_waves;
+                            }
+                            if (cand < prm.n_waves && cand != blockIdx.x &&
+                                wb_cas(work + RTC_WORK_STATES + cand, RTC_MB_HUNGRY, RTC_MB_FILLING))
+                                target = (int)cand;
+                        }
+                    }
+                    share_round++;
+                    target = __builtin_amdgcn_readfirstlane(target);
+                    if (target >= 0) {
+                        unsigned long long *box = (unsigned long long *)((char *)work + RTC_WORK_MBOX_BYTES) +
+                                                  (size_t)target * 64u * RTC_MBOX_ITEM_U64;
+                        if (alive && sp > 0) {
+                            const unsigned rank = __builtin_amdgcn_mbcnt_hi(
+                                (unsigned)(don2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)don2, 0u));
+                            const Pending q = pend[pbase];
+                            const double qm = STATS ? pend_mult[pbase] : 0.;
+                            pbase = (pbase + 1) & (RTC_MAX_DEPTH_STACK - 1);
+                            sp--;
+                            if (!shared) {
+                                zero_pixel();
+                                shared = true;
+                            }
+                            unsigned long long *it = box + rank * RTC_MBOX_ITEM_U64;
+                            wb_store64(it + 0, f64_bits(q.o.x)), wb_store64(it + 1, f64_bits(q.o.y));
+                            wb_store64(it + 2, f64_bits(q.o.z)), wb_store64(it + 3, f64_bits(q.d.x));
+                            wb_store64(it + 4, f64_bits(q.d.y)), wb_store64(it + 5, f64_bits(q.d.z));
+                            wb_store64(it + 6, f64_bits(q.w)), wb_store64(it + 7, f64_bits(qm));
+                            wb_store64(it + 8, ((unsigned long long)pix << 32) | (unsigned)q.remaining);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the rays are visible before the count
+                        if (lane == 0) {
+                            wb_store(work + RTC_WORK_COUNTS + target, (unsigned)__popcll(don2));
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                            wb_store(work + RTC_WORK_STATES + target, RTC_MB_FULL);
+                            atomicSub(work + RTC_WORK_HUNGRY, 1u);
+                        }
                     }
                 }
             }
-            if (__ballot(alive) == 0ull) break;  // no pixel in flight and none left: the wave is done
+            if (__ballot(alive) == 0ull) {
+                // no pixel in flight and none left
+                if (!(PERSISTENT && prm.share)) break;  // the wave is done
+                int got = 0;
+                if (lane == 0) {
+                    unsigned *my_state = work + RTC_WORK_STATES + blockIdx.x;
+                    atomicSub(work + RTC_WORK_BUSY, 1u);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    wb_store(my_state, RTC_MB_HUNGRY);
+                    atomicAdd(work + RTC_WORK_HUNGRY, 1u);
+                    const unsigned slot = atomicAdd(work + RTC_WORK_HINT_TAIL, 1u);
+                    wb_store(work + RTC_WORK_HINTS + (slot & 255u), blockIdx.x);
+                    // waits for rays, or for every wave to have run out of its own (bounded: a donor between its
+                    // claim and RTC_MB_FULL runs straight-line code; the cap only guards against the unforeseen)
+                    for (unsigned spin = 0;; spin++) {
+                        const unsigned stt = wb_load(my_state);
+                        if (stt == RTC_MB_FULL) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                            got = (int)wb_load(work + RTC_WORK_COUNTS + blockIdx.x);
+                            break;
+                        }
+                        if (stt == RTC_MB_HUNGRY && (wb_load(work + RTC_WORK_BUSY) == 0u || spin > (1u << 20)) &&
+                            wb_cas(my_state, RTC_MB_HUNGRY, RTC_MB_CLOSED)) {
+                            atomicSub(work + RTC_WORK_HUNGRY, 1u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(127);
+                    }
+                    if (got > 0) atomicAdd(work + RTC_WORK_BUSY, 1u);
+                }
+                got = __builtin_amdgcn_readfirstlane(got);
+                if (got <= 0) break;  // the frame is done
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if ((int)lane < got) {
+                    const unsigned long long *it = my_box + lane * RTC_MBOX_ITEM_U64;
+                    const V3 qo = mk(bits_f64(wb_load64(it + 0)), bits_f64(wb_load64(it + 1)), bits_f64(wb_load64(it + 2)));
+                    const V3 qd = mk(bits_f64(wb_load64(it + 3)), bits_f64(wb_load64(it + 4)), bits_f64(wb_load64(it + 5)));
+                    const double qw = bits_f64(wb_load64(it + 6)), qm = bits_f64(wb_load64(it + 7));
+                    const unsigned long long pr = wb_load64(it + 8);
+                    adopt((unsigned)(pr >> 32), qo, qd, qw, qm, (int)(unsigned)pr);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the mailbox has been read)
+                if (lane == 0) wb_store(work + RTC_WORK_STATES + blockIdx.x, RTC_MB_IDLE);
+            }
         }
         STAGE_END(ST_CYC_REFILL);
         if (STATS) {
@@ -1460,6 +1579,9 @@ static void launch_variant(const DScene &scene, DRenderParams &params, double *d
         static const unsigned refill_env = getenv("RTC_REFILL_MIN") ? (unsigned)atoi(getenv("RTC_REFILL_MIN")) : 0u;
         params.refill_min = refill_env ? refill_env : RTC_REFILL_MIN;
         params.dyn_base = waves;  // wave b renders tile b first
+        static const int share_env = getenv("RTC_SHARE") ? atoi(getenv("RTC_SHARE")) : 1;
+        params.share = (share_env != 0 && waves <= RTC_MAX_WAVES) ? 1u : 0u;
+        params.n_waves = waves;
         static const unsigned stay_env = getenv("RTC_STAY_MIN") ? (unsigned)atoi(getenv("RTC_STAY_MIN")) : 0u;
         params.stay_min = stay_env ? stay_env : RTC_STAY_MIN;
         hipLaunchKernelGGL((k_render<STATS, GROUPS, PATTERNS, true, QNODES>), dim3(waves), dim3(RTC_WAVE), 0, st, scene,
@@ -1467,6 +1589,7 @@ static void launch_variant(const DScene &scene, DRenderParams &params, double *d
     } else {
         params.refill_min = RTC_WAVE;
         params.dyn_base = tiles;
+        params.share = 0u, params.n_waves = tiles;
         hipLaunchKernelGGL((k_render<STATS, GROUPS, PATTERNS, false, QNODES>), dim3(tiles), dim3(RTC_WAVE), 0, st, scene,
                            params, d_rgb, ds, d_work);
     }
@@ -1488,7 +1611,7 @@ int launch_render(const DScene &scene, const DRenderParams &params_in, double *d
     if (tiles == 0) return RTC_OK;
     hipStream_t st = (hipStream_t)stream;
     // the tile counters of the persistent grid start at zero for every launch
-    if (params.persistent && hipMemsetAsync(d_work, 0, RTC_SHARDS * 128u, st) != hipSuccess) {
+    if (params.persistent && hipMemsetAsync(d_work, 0, RTC_WORK_RESET_BYTES, st) != hipSuccess) {
         set_error("hipMemsetAsync(work counter) failed");
         return RTC_ERR_HIP;
     }

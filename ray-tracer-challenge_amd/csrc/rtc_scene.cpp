@@ -748,10 +748,15 @@ int Scene::upload(int dev) {
     if ((rc = upload_vec(*this, zeros, dst))) return rc;
     d_stats = const_cast<uint64_t *>(dst);
     {
-        std::vector<unsigned> wz(8 * 32, 0u);  // RTC_SHARDS counters, one 128-byte line each
-        const unsigned *dw = nullptr;
-        if ((rc = upload_vec(*this, wz, dw))) return rc;
-        d_work = const_cast<unsigned *>(dw);
+        // tile counters + end-of-frame ray exchange of the persistent schedule (layout: rtc_types.h)
+        void *pw = nullptr;
+        if (hipMalloc(&pw, RTC_WORK_TOTAL_BYTES) != hipSuccess || hipMemset(pw, 0, RTC_WORK_RESET_BYTES) != hipSuccess) {
+            set_error("hipMalloc(%zu) for the work buffer failed", (size_t)RTC_WORK_TOTAL_BYTES);
+            return RTC_ERR_HIP;
+        }
+        device_allocs.push_back(pw);
+        device_bytes += RTC_WORK_TOTAL_BYTES;
+        d_work = (unsigned *)pw;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
             set_error("hipGetDeviceProperties failed");

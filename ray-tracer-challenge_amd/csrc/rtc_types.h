@@ -168,6 +168,27 @@ struct DScene {
     DCamera cam;
 };
 
+// Work buffer of the persistent schedule (one per scene, device memory; the first RTC_WORK_RESET_BYTES are zeroed
+// before every launch).  u32 indices unless noted:
+//   [0, 256)            tile counters, RTC_SHARDS of them on 128-byte lines
+//   RTC_WORK_BUSY       waves that still have rays of their own to trace
+//   RTC_WORK_HUNGRY     waves waiting for rays of others (a hint: donors skip the search when it is 0)
+//   RTC_WORK_HINT_TAIL  number of hints published so far; RTC_WORK_HINTS: ring of 256 wave ids that went hungry
+//   RTC_WORK_STATES     per wave: mailbox state (RTC_MB_*);  RTC_WORK_COUNTS: per wave: rays in its mailbox
+//   byte RTC_WORK_MBOX_BYTES on: per wave one mailbox of 64 rays x RTC_MBOX_ITEM_U64 x 8 bytes
+#define RTC_MAX_WAVES 4096u
+#define RTC_WORK_BUSY 256u
+#define RTC_WORK_HUNGRY 288u
+#define RTC_WORK_HINT_TAIL 320u
+#define RTC_WORK_HINTS 512u
+#define RTC_WORK_STATES 1024u
+#define RTC_WORK_COUNTS (RTC_WORK_STATES + RTC_MAX_WAVES)
+#define RTC_WORK_RESET_BYTES ((RTC_WORK_COUNTS + RTC_MAX_WAVES) * 4u)
+#define RTC_WORK_MBOX_BYTES RTC_WORK_RESET_BYTES
+#define RTC_MBOX_ITEM_U64 10u
+#define RTC_WORK_TOTAL_BYTES ((size_t)RTC_WORK_MBOX_BYTES + (size_t)RTC_MAX_WAVES * 64u * RTC_MBOX_ITEM_U64 * 8u)
+enum { RTC_MB_IDLE = 0, RTC_MB_HUNGRY = 1, RTC_MB_FILLING = 2, RTC_MB_FULL = 3, RTC_MB_CLOSED = 4 };
+
 struct DRenderParams {
     uint32_t depth;
     uint32_t tile_rows, tile_index, tile_count;
@@ -178,6 +199,8 @@ struct DRenderParams {
     uint32_t dyn_base;          // first tile handed out through the device-wide counters (= grid size)
     uint32_t stay_min;          // waiting lanes at which a wave leaves the traversal loop to serve them (persistent)
     uint32_t refill_min;        // free lanes a wave waits for before it assigns new pixels (1..64)
+    uint32_t share;             // 1: at the end of a frame waves without work take over waiting rays of other waves
+    uint32_t n_waves;           // size of the persistent grid
     uint32_t tile_order;        // 0: tiles are handed out top row first, 1: bottom row first
     uint32_t leaf_den;          // primitive tests run when at least 1/leaf_den of the traversing lanes wait at a leaf
 };
