@@ -1142,8 +1142,10 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 const unsigned long long dead = __ballot(!alive);
                 if (!(exhausted && r_next == r_end)) {
                     if ((unsigned)__popcll(dead) >= prm.refill_min) idle |= dead;
-                } else if (__ballot(alive && sp > 0) != 0ull) {
-                    idle |= dead;  // tail: they can take over a waiting ray
+                } else if (idle != 0ull || __ballot(alive && sp > 0) != 0ull) {
+                    // tail: free lanes can take over a waiting ray, and in a wave that is mostly empty a finished lane
+                    // is served at once -- what is left of the frame is a chain of dependent rays, not throughput
+                    idle |= dead;
                 }
                 if ((unsigned)__popcll(idle) >= prm.stay_min) break;
             }
