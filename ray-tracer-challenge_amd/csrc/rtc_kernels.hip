@@ -705,7 +705,10 @@ DEV double lane_f64(double v, int src) {
 //   2. ordered traversal of the binary BVH with the per-lane stack in LDS; leaf records come through the
 //      vector cache, one 128-byte record (one cache line) per test.
 // Template flags remove state a scene does not need: GROUPS (any primitive has an ancestor group: ray cache
-// in group space, chain walks), PATTERNS (any material has a pattern).
+// in group space, chain walks), PATTERNS (any material has a pattern); QNODES selects the 32-byte quantised nodes
+// and the 64-byte sphere leaves of large hierarchies; PERSISTENT the schedule: a grid of resident waves that draw
+// tiles from device counters, refill free lanes pixel by pixel and, once the tiles have run out, pass waiting rays
+// to free lanes of the same wave and -- through per-wave mailboxes in `work` -- of other waves.
 template <bool STATS, bool GROUPS, bool PATTERNS, bool PERSISTENT, bool QNODES>
 __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DRenderParams prm,
                                                                      double *__restrict__ out,
