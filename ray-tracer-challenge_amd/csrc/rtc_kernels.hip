@@ -593,9 +593,8 @@ enum ParkSlot {
     PK_COLOR = 9,   // accumulated pixel colour (3)
     PK_SURFACE = 12,  // sum of Material::lighting over the lights evaluated so far (3)
     PK_W = 15,
-    PK_N1 = 16,
-    PK_N2 = 17,
-    PK_COUNT = 18
+    PK_KR = 16,  // Schlick reflectance of the hit (1 unless the material is both reflective and transparent)
+    PK_COUNT = 17
 };
 typedef __attribute__((address_space(3))) double lds_f64;  // an LDS pointer the compiler can not mistake for flat
 DEV void park3(lds_f64 *base, int slot, V3 v) {
@@ -1312,7 +1311,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         // state machine
         // =====================================================================================
         bool begin_lights = false, finish = false, next_ray = false, need_shadow = false;
-        double f_refl = 0., f_transp = 0.;  // the hit material's reflectivity / transparency when `finish` is set
+        double f_refl = 0.;  // the hit material's reflectivity when `finish` is set
         SUB_BEGIN();
         if (T.mode == MODE_CLOSEST) {
             // World::color_at, world.rs:30-38
@@ -1335,8 +1334,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 park3(pk, PK_POINT, h_point);
                 park3(pk, PK_EYE, h_eye);
                 park3(pk, PK_NORMAL, n);
-                pk[PK_N1 * RTC_WAVE] = 1.;
-                pk[PK_N2 * RTC_WAVE] = 1.;
+                pk[PK_KR * RTC_WAVE] = 1.;
                 CNT(ST_SHADED, 1);
                 if (remaining > 0 && m_transparency != 0.) {
                     // containers loop (intersection.rs:150-179) in streaming form: second pass over the same
@@ -1367,8 +1365,42 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 n1 = ri_other;
                 n2 = ri_hit;
             }
-            pk[PK_N1 * RTC_WAVE] = n1;
-            pk[PK_N2 * RTC_WAVE] = n2;
+            // refracted_color (world.rs:108-147) is known as soon as n1/n2 are, and its ray goes to the ring NOW, before
+            // the shadow rays of this hit: what the end of a frame waits for is a chain of refractions through glass, and
+            // this way a free lane can start on the next link while this one still lights the hit.  (The containers pass
+            // ran because remaining > 0 and the material is transparent; ring order and arithmetic are unchanged.)
+            {
+                const DMaterial &m = s.materials[h_mat];
+                const double m_refl = m.reflectivity, m_transp = m.transparency;
+                const V3 h_normal = unpark3(pk, PK_NORMAL);
+                const V3 h_eye = unpark3(pk, PK_EYE);
+                double kr = 1., kt = 1.;
+                if (m_refl > 0. && m_transp > 0.) {
+                    const double r = schlick(n1, n2, h_eye, h_normal);
+                    CNT(ST_SCHLICK, 1);
+                    kr = r;
+                    kt = 1. - r;
+                }
+                pk[PK_KR * RTC_WAVE] = kr;  // reflected_color's share, used by shade_hit's tail below
+                const double n_ratio = n1 / n2;
+                const double cos_i = dot(h_eye, h_normal);
+                const double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+                CNT(ST_REFRACT, 1);
+                if (!(sin2_t > 1.)) {
+                    if (sp < RTC_MAX_DEPTH_STACK) {
+                        const double cos_t = sqrt(1. - sin2_t);
+                        Pending &q = pend[RTC_PEND(sp)];
+                        q.o = unpark3(pk, PK_POINT) - h_normal * RTC_EPS;  // under_point
+                        q.d = h_normal * (n_ratio * cos_i - cos_t) - h_eye * n_ratio;
+                        q.w = pk[PK_W * RTC_WAVE] * (nl * (m_transp * kt));
+                        q.remaining = remaining;  // Q2: not decremented (world.rs:142)
+                        if (STATS) pend_mult[RTC_PEND(sp)] = mult * nl;
+                        sp++;
+                    } else {
+                        CNT(ST_OVERFLOW, 1);
+                    }
+                }
+            }
             begin_lights = true;
         }
         SUB_END(ST_CONTAINER);
@@ -1416,7 +1448,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 if (li < s.n_lights)
                     need_shadow = true;
                 else
-                    finish = true, f_refl = m.reflectivity, f_transp = m.transparency;
+                    finish = true, f_refl = m.reflectivity;
             }
         }
         SUB_END(ST_SHADOW);
@@ -1430,68 +1462,21 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             const double w = pk[PK_W * RTC_WAVE];
             park3(pk, PK_COLOR, unpark3(pk, PK_COLOR) + unpark3(pk, PK_SURFACE) * w);
             next_ray = true;
-            if (remaining > 0) {
-                const bool refl = f_refl != 0.;
-                const bool refr = f_transp != 0.;
-                if (refl || refr) {
-                    // the parked context is read where it is used (volatile: one LDS read per use) so that
-                    // nothing of it is held in registers -- or spilled to scratch -- across the square roots
-                    const V3 h_normal = unpark3(pk, PK_NORMAL);
-                    const V3 h_eye = unpark3(pk, PK_EYE);
-                    double kr = 1., kt = 1.;
-                    if (f_refl > 0. && f_transp > 0.) {
-                        const double r = schlick(pk[PK_N1 * RTC_WAVE], pk[PK_N2 * RTC_WAVE], h_eye, h_normal);
-                        CNT(ST_SCHLICK, 1);
-                        kr = r;
-                        kt = 1. - r;
-                    }
-                    bool refracted = false;
-                    if (refr) {
-                        // refracted_color, world.rs:108-147
-                        const double n_ratio = pk[PK_N1 * RTC_WAVE] / pk[PK_N2 * RTC_WAVE];
-                        const double cos_i = dot(h_eye, h_normal);
-                        const double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
-                        CNT(ST_REFRACT, 1);
-                        if (!(sin2_t > 1.)) {
-                            if (sp < RTC_MAX_DEPTH_STACK) {
-                                // written straight into its stack slot: nothing of it is held across the reflection
-                                const double cos_t = sqrt(1. - sin2_t);
-                                Pending &q = pend[RTC_PEND(sp)];
-                                q.o = unpark3(pk, PK_POINT) - h_normal * RTC_EPS;  // under_point
-                                q.d = h_normal * (n_ratio * cos_i - cos_t) - h_eye * n_ratio;
-                                q.w = w * (nl * (f_transp * kt));
-                                q.remaining = remaining;  // Q2: not decremented (world.rs:142)
-                                if (STATS) pend_mult[RTC_PEND(sp)] = mult * nl;
-                                refracted = true;
-                            } else {
-                                CNT(ST_OVERFLOW, 1);
-                            }
-                        }
-                    }
-                    if (refl) {
-                        // both children: the refracted ray waits in the stack while the reflected one is traced
-                        if (refracted) sp++;
-                        // reflected_color, world.rs:93-106
-                        ray.o = unpark3(pk, PK_POINT) + h_normal * RTC_EPS;  // over_point
-                        ray.d = reflect(-h_eye, h_normal);
-                        pk[PK_W * RTC_WAVE] = w * (nl * (f_refl * kr));
-                        remaining -= 1;
-                    } else if (refracted) {
-                        // the only child: it is the next ray
-                        const Pending &q = pend[RTC_PEND(sp)];
-                        ray.o = q.o, ray.d = q.d;
-                        pk[PK_W * RTC_WAVE] = q.w;
-                    }
-                    if (refl || refracted) {
-                        if (STATS) mult = mult * nl;
-                        next_ray = false;
-                        T.mode = MODE_CLOSEST;
-                        T.lim = inf, T.prim = -1;
-                        CNT(ST_SECONDARY, 1);
-                        CNT(ST_SECONDARY_REF, mult);
-                        rays++;
-                    }
-                }
+            if (remaining > 0 && f_refl != 0.) {
+                // reflected_color, world.rs:93-106 (the refracted ray, if any, already waits in the ring)
+                const V3 h_normal = unpark3(pk, PK_NORMAL);
+                const V3 h_eye = unpark3(pk, PK_EYE);
+                ray.o = unpark3(pk, PK_POINT) + h_normal * RTC_EPS;  // over_point
+                ray.d = reflect(-h_eye, h_normal);
+                pk[PK_W * RTC_WAVE] = w * (nl * (f_refl * pk[PK_KR * RTC_WAVE]));
+                remaining -= 1;
+                if (STATS) mult = mult * nl;
+                next_ray = false;
+                T.mode = MODE_CLOSEST;
+                T.lim = inf, T.prim = -1;
+                CNT(ST_SECONDARY, 1);
+                CNT(ST_SECONDARY_REF, mult);
+                rays++;
             }
         }
         SUB_END(ST_SECONDARY);
