@@ -789,16 +789,22 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
         const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
         const unsigned y = canvas_row(prm, l);
-        if (x < s.cam.hsize && l < prm.local_rows) {
+        if (x < s.hsize && l < prm.local_rows) {
             // camera.rs:72,78: rows 0..vsize-1 and columns 0..hsize-1 (exclusive) -- Q1
-            if ((x + 1u < s.cam.hsize) && (y + 1u < s.cam.vsize)) {
+            if ((x + 1u < s.hsize) && (y + 1u < s.vsize)) {
                 // Camera::ray_for_pixel, camera.rs:41-59
-                const double xo = ((double)x + 0.5) * s.cam.pixel_size;
-                const double yo = ((double)y + 0.5) * s.cam.pixel_size;
-                const double wx = s.cam.half_width - xo;
-                const double wy = s.cam.half_height - yo;
-                const V3 pixel = xf_point(s.cam.inv, mk(wx, wy, -1.));
-                ray.o = xf_point(s.cam.inv, mk(0., 0., 0.));
+                // (the pointer is made opaque here so that the camera is fetched -- through the scalar cache -- when a
+                // pixel starts, not hoisted into registers for the whole kernel)
+                typedef const __attribute__((address_space(4))) DCamera *const_cam_ptr;
+                const DCamera *cam_raw = s.cam;
+                asm volatile("" : "+s"(cam_raw));
+                const const_cam_ptr cam = (const_cam_ptr)cam_raw;
+                const double xo = ((double)x + 0.5) * cam->pixel_size;
+                const double yo = ((double)y + 0.5) * cam->pixel_size;
+                const double wx = cam->half_width - xo;
+                const double wy = cam->half_height - yo;
+                const V3 pixel = xf_point(cam->inv, mk(wx, wy, -1.));
+                ray.o = xf_point(cam->inv, mk(0., 0., 0.));
                 ray.d = normalize(pixel - ray.o);
                 park3(pk, PK_COLOR, mk(0., 0., 0.));
                 pk[PK_W * RTC_WAVE] = 1.;
@@ -812,7 +818,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 CNT(ST_PRIMARY, 1);
                 alive = true;
             } else {
-                double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
+                double *px = out + ((size_t)l * s.hsize + x) * 3u;
                 px[0] = 0., px[1] = 0., px[2] = 0.;  // Canvas::new: black
             }
         }
@@ -823,7 +829,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
         const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
         const V3 color = unpark3(pk, PK_COLOR);
-        double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
+        double *px = out + ((size_t)l * s.hsize + x) * 3u;
         if (PERSISTENT && shared) {
             // one of several lanes that traced parts of this pixel's ray tree (the pixel was zeroed when the first
             // part was handed over): the order of these few additions is the only run-to-run freedom of a frame
@@ -855,7 +861,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         const unsigned tile = prm.tile_order ? n_tiles - 1u - (pix >> 6) : (pix >> 6), q = pix & 63u;
         const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
         const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
-        double *px = out + ((size_t)l * s.cam.hsize + x) * 3u;
+        double *px = out + ((size_t)l * s.hsize + x) * 3u;
         px[0] = 0., px[1] = 0., px[2] = 0.;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the stores are in L2 before any lane adds to them)
     };

@@ -668,7 +668,11 @@ int Scene::upload(int dev) {
     }
     device = dev;
     dscene = DScene{};
-    dscene.cam = cam;
+    {
+        std::vector<DCamera> cv(1, cam);
+        if (int rc0 = upload_vec(*this, cv, dscene.cam)) return rc0;
+        dscene.hsize = cam.hsize, dscene.vsize = cam.vsize;
+    }
     int rc;
     if ((rc = upload_vec(*this, xforms, dscene.xforms))) return rc;
     if ((rc = upload_vec(*this, chains, dscene.chains))) return rc;

@@ -165,7 +165,10 @@ struct DScene {
     int32_t pad0;
     double q_org[3], q_cell[3]; // box plane along axis a = q_org[a] + q * q_cell[a]
     double root_min[3], root_max[3];
-    DCamera cam;
+    // The camera is read once per pixel: it stays in memory (32 fewer argument registers, which the loops would
+    // otherwise pay for with v_readlane reloads of other arguments) and only its two sizes travel by value.
+    const DCamera *cam;
+    uint32_t hsize, vsize;
 };
 
 // Work buffer of the persistent schedule (one per scene, device memory; the first RTC_WORK_RESET_BYTES are zeroed
