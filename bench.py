@@ -40,6 +40,21 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop (FMA) x 2.4 
 TILE_ROWS = 8
 
 
+def compare(a, b):
+    """two canvases: max |delta| in f64 and the 8-bit channels (Canvas::to_ppm's scale_and_clamp, canvas.rs:86-89)"""
+    import numpy as np
+
+    def to8(img):
+        v = np.asarray(img, dtype=np.float64) * 255.0
+        r = np.where(np.isnan(v), 0.0, np.sign(v) * np.floor(np.abs(v) + 0.5))
+        return np.clip(r, 0, 255).astype(np.int32)
+    d = np.abs(np.asarray(a) - np.asarray(b))
+    d8 = np.abs(to8(a) - to8(b))
+    return dict(max_abs=float(np.nanmax(d)) if d.size else 0.0, nan=int(np.isnan(d).sum()),
+                max_8bit=int(d8.max()) if d8.size else 0, mismatched_channels=int((d8 > 0).sum()),
+                pixels_over_1=int((d8.max(axis=-1) > 1).sum()) if d8.size else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +71,9 @@ def main():
     ap.add_argument("--extra-stress", action="store_true", help="include the (slow) stress scene in --extra")
     ap.add_argument("--extra", action="store_true", help="(default at N=1) also time the reference sample scenes")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--fp-mode", default="strict", choices=["strict", "fast"],
+                    help="flavour of the TIMED frames (the headline is strict; the other flavour is reported beside it)")
+    ap.add_argument("--no-flavours", action="store_true", help="skip the comparison frame of the other fp flavour")
     args = ap.parse_args()
 
     import numpy as np
@@ -95,6 +113,9 @@ def main():
     hsize, vsize = cam.hsize, cam.vsize
     tile = dict(tile_rows=TILE_ROWS, tile_index=rank, tile_count=world_size) if distributed else {}
     ropts = dict(tile)
+    fp_mode = 1 if args.fp_mode == "fast" else 0
+    if fp_mode:
+        ropts["fp_mode"] = fp_mode
     if args.schedule:
         ropts["schedule"] = args.schedule
     if args.use_bvh:
@@ -112,7 +133,9 @@ def main():
     canvas_ext = None
     index = None
     if distributed and rank == 0:
-        gather_list = [torch.empty_like(buf) for _ in range(world_size)]
+        # one preallocated buffer: rank r's rows land in gathered[r], and the de-interleave reads it in place
+        gathered = torch.empty((world_size,) + tuple(buf.shape), dtype=torch.float64, device=dev)
+        gather_list = [gathered[r] for r in range(world_size)]
         canvas_ext = torch.zeros((vsize + 1, hsize, 3), dtype=torch.float64, device=dev)  # +1: dump row for padding
         idx = np.full((world_size, max_rows), vsize, dtype=np.int64)
         for r in range(world_size):
@@ -131,7 +154,7 @@ def main():
             return
         dist.gather(buf, gather_list, dst=0)
         if rank == 0:
-            canvas_ext.index_copy_(0, index, torch.cat(gather_list, dim=0))
+            canvas_ext.index_copy_(0, index, gathered.view(-1, hsize, 3))
 
     def step():
         scene.render_device(buf.data_ptr(), stream.cuda_stream, **ropts)
@@ -147,7 +170,7 @@ def main():
     scene.render_device(buf.data_ptr(), stream.cuda_stream, collect_stats=True, **ropts)
     st = scene.stats()
     keys = ["primary_rays", "shadow_rays", "secondary_rays", "secondary_rays_reference", "box_tests",
-            "shaded_hits", "light_evals", "container_passes", "xform_levels", "overflow"]
+            "shaded_hits", "light_evals", "container_passes", "xform_levels", "overflow", "shadow_rays_skipped"]
     vec = [float(st[k]) for k in keys] + [float(x) for x in st["prim_tests"]] + [st["algorithmic_flops"]]
     if distributed:
         t = torch.tensor(vec, device=dev, dtype=torch.float64)
@@ -228,11 +251,14 @@ def main():
                 args.workload, WORKLOADS[args.workload][0], hsize, vsize, (hsize - 1) * (vsize - 1)),
             "sharding": "interleaved %d-row tiles over %d rank(s); RCCL gather to rank 0" % (TILE_ROWS, world_size)
             if distributed else "single GPU, whole frame in one launch",
-            "fp_mode": "strict (no FMA contraction)",
+            "fp_mode": "fast (FMA contraction, shared reciprocals)" if fp_mode else "strict (no FMA contraction)",
         },
         "rays_per_frame": {
             "primary": frame["primary_rays"], "shadow": frame["shadow_rays"], "secondary": frame["secondary_rays"],
             "total_unique": rays_per_frame,
+            # is_shadowed queries whose answer cannot reach the pixel (light behind the surface, material.rs:49-52):
+            # the reference traces them, this kernel does not, and `value` does not count them
+            "shadow_skipped_light_behind_surface": frame["shadow_rays_skipped"],
             "secondary_reference_equivalent": frame["secondary_rays_reference"],
         },
         "work_per_frame": {"box_tests": frame["box_tests"], "prim_tests": frame_prim_tests,
@@ -256,6 +282,28 @@ def main():
         },
     }
 
+    if not args.no_flavours and not distributed:
+        # headline frame in the other flavour (one untimed + two timed launches) and its distance from the timed one
+        other = 0 if fp_mode else 1
+        kw = dict(ropts, fp_mode=other)
+        timed_canvas = buf.cpu().numpy()
+        scene.render_device(buf.data_ptr(), stream.cuda_stream, **kw)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(2):
+            scene.render_device(buf.data_ptr(), stream.cuda_stream, **kw)
+        b.record(stream)
+        torch.cuda.synchronize(dev)
+        scene.check()
+        o_ms = a.elapsed_time(b) / 2
+        rep = compare(buf.cpu().numpy(), timed_canvas)
+        out["other_flavour"] = {"fp_mode": "strict" if fp_mode else "fast", "frame_ms": o_ms,
+                                "roofline_frac": local_flops / (o_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                "max_abs_vs_timed": rep["max_abs"], "max_8bit_vs_timed": rep["max_8bit"],
+                                "channels_differing_8bit": rep["mismatched_channels"]}
+        # leave the timed flavour's frame in `buf` for the parity check below
+        scene.render_device(buf.data_ptr(), stream.cuda_stream, **ropts)
+        torch.cuda.synchronize(dev)
     if not args.no_extra and not distributed:
         extra = {}
         for wl in WORKLOADS:
@@ -282,7 +330,29 @@ def main():
             ms = a.elapsed_time(b) / reps
             rays = st2["primary_rays"] + st2["shadow_rays"] + st2["secondary_rays"]
             extra[wl] = {"frame_ms": ms, "Mrays_per_s": rays / ms / 1e3, "rays": rays,
-                         "tflops": st2["algorithmic_flops"] / ms / 1e9}
+                         "tflops": st2["algorithmic_flops"] / ms / 1e9,
+                         "roofline_frac": st2["algorithmic_flops"] / ms / 1e9 / FP64_VALU_PEAK_TFLOPS}
+            # the reference-shaped call (Camera::render -> Canvas): kernel + device-to-host copy of the canvas into the
+            # caller's pageable buffer, end to end, second call (the first one allocates the kept buffers)
+            host = np.empty((c2.vsize, c2.hsize, 3), dtype=np.float64)
+            s2.render(out=host, **kw2)
+            t1 = time.perf_counter()
+            s2.render(out=host, **kw2)
+            extra[wl]["render_call_ms"] = (time.perf_counter() - t1) * 1e3
+            if not args.no_flavours:
+                # the other fp flavour on the same frame: time and distance from the strict canvas
+                a.record(stream)
+                for _ in range(reps):
+                    s2.render_device(b2.data_ptr(), stream.cuda_stream, fp_mode=1, **kw2)
+                b.record(stream)
+                torch.cuda.synchronize(dev)
+                fast_ms = a.elapsed_time(b) / reps
+                fast = b2.cpu().numpy()
+                rep = compare(fast, host)
+                extra[wl]["fast_flavour"] = {"frame_ms": fast_ms, "max_abs_vs_strict": rep["max_abs"],
+                                             "max_8bit_vs_strict": rep["max_8bit"],
+                                             "channels_differing_8bit": rep["mismatched_channels"],
+                                             "roofline_frac": st2["algorithmic_flops"] / fast_ms / 1e9 / FP64_VALU_PEAK_TFLOPS}
             s2.close()
         out["extra_workloads"] = extra
 
@@ -293,6 +363,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import scene_feed as sf
         threads = min(os.cpu_count() or 1, 16)
+        gpu_canvas = buf.cpu().numpy()  # the frame of the timed region
+        max_abs, mism8, over1, npix, nan = 0.0, 0, 0, 0, 0
         ow = sf.to_oracle(world, cam)
         heavy = args.workload == "stress_4k"  # ~3 ms of CPU work per ray (106k primitives per ray)
         rstep, cstep = (135, 480) if heavy else (48, 48)
@@ -300,8 +372,14 @@ def main():
             rstep = cstep = args.cpu_sample_stride
         cpu_rays, cpu_secs, cpu_pixels, offset = 0, 0.0, 0, 0
         while cpu_secs < 10.0 and offset < rstep:
-            ow.render(threads=threads, subset=(offset, vsize, rstep, cstep))
+            ref = ow.render(threads=threads, subset=(offset, vsize, rstep, cstep))
             cs = ow.last_stats
+            # north_star: "a reported per-pixel max-abs float delta" -- the oracle's pixels against the GPU frame
+            rows, cols = slice(offset, vsize - 1, rstep), slice(0, hsize - 1, cstep)
+            rep = compare(gpu_canvas[rows, cols], ref[rows, cols])
+            max_abs, nan = max(max_abs, rep["max_abs"]), nan + rep["nan"]
+            mism8, over1 = mism8 + rep["mismatched_channels"], over1 + rep["pixels_over_1"]
+            npix += ref[rows, cols].shape[0] * ref[rows, cols].shape[1]
             cpu_rays += cs["primary"] + cs["shadow"] + cs["secondary"]
             cpu_pixels += cs["primary"]
             cpu_secs += cs["seconds"]
@@ -310,6 +388,10 @@ def main():
             if not heavy and cpu_secs < 1.0 and rstep > 2 and offset == 1:
                 rstep, cstep, offset = max(1, rstep // 4), max(1, cstep // 4), 0
                 cpu_rays, cpu_secs, cpu_pixels = 0, 0.0, 0
+                max_abs, mism8, over1, npix, nan = 0.0, 0, 0, 0, 0
+        out["parity"] = {"against": "C oracle (oracle/rtc_oracle.c), same frame, pixels on a regular grid",
+                         "pixels": npix, "max_abs": max_abs, "mismatched_8bit": mism8, "pixels_over_1_of_255": over1,
+                         "nan": nan, "within_tolerance": bool(over1 == 0 and nan == 0)}
         out["cpu_baseline"] = {
             "value": cpu_rays / max(cpu_secs, 1e-9) / 1e6,
             "unit": "Mrays/s",

@@ -69,14 +69,28 @@ typedef struct rtc_material {
 
 /* Render options.  Zero-initialise and call rtc_render_opts_default(). */
 typedef struct rtc_render_opts {
-    uint32_t depth;      /* bounce budget; the reference uses the literal 5 (camera.rs:80) */
-    uint32_t tile_rows;  /* rows per row tile for multi-GPU sharding (0 = whole image is one tile) */
+    uint32_t depth;      /* bounce budget; the reference uses the literal 5 (camera.rs:80).  At most 8: the per-lane
+                            stack of waiting refracted rays holds one entry per distinct `remaining` value (a larger
+                            value is refused with RTC_ERR_INVALID) */
+    uint32_t tile_rows;  /* rows per row tile for multi-GPU sharding (0 = whole image is one tile); must be set
+                            (non-zero) whenever tile_count > 1 */
     uint32_t tile_index; /* this rank renders tiles t with t % tile_count == tile_index */
     uint32_t tile_count; /* number of ranks (1 = everything) */
     uint32_t use_bvh;    /* 0 = auto, 1 = force BVH traversal, 2 = force brute-force linear scan */
     uint32_t collect_stats; /* 1 = run the counting variant of the kernel and fill the ray/test counters */
     uint32_t schedule;   /* 0 = auto, 1 = one workgroup per 8x8 tile, 2 = persistent grid with lane refill */
-    uint32_t reserved[1];
+    uint32_t exchange;   /* persistent schedule only.  0 = auto (on): at the end of a frame lanes and waves without work
+                            take over waiting rays of busy ones and ADD their part to the pixel with f64 atomics -- the
+                            order of those few additions is timing dependent (observed <= 2e-15).  1 = off: every pixel
+                            is traced by one lane from start to end; the frame is bit-reproducible and bit-equal to
+                            schedule 1's */
+    uint32_t max_rays_per_pixel; /* guard against runaway ray trees (refraction keeps the bounce budget, world.rs:142):
+                            a lane that traces more rays than this for one pixel gives up, the pixel becomes NaN and the
+                            call reports RTC_ERR_OVERFLOW.  0 = default (65536) */
+    uint32_t fp_mode;    /* 0 = strict: no FMA contraction, IEEE division and sqrt, the reference's operation order (the
+                            parity flavour).  1 = fast: contraction and shared reciprocals allowed; within 1/255 per
+                            8-bit channel of strict, not bit-equal */
+    uint32_t reserved[6];
 } rtc_render_opts;
 
 /* Work counters (filled when collect_stats != 0) and timing of the last launch. */
@@ -95,6 +109,9 @@ typedef struct rtc_stats {
     uint64_t schlick_evals;
     uint64_t refract_evals;
     uint64_t overflow;        /* lanes that hit the iteration cap (0 in a valid render) */
+    uint64_t shadow_rays_skipped; /* is_shadowed queries whose answer cannot change the pixel (the light is behind the
+                                 surface: material.rs:49-52 sets diffuse and specular to black whatever the intensity)
+                                 and that were therefore not traced; the reference traces shadow_rays + this many */
     uint64_t diag[10];        /* counting kernel only: shader cycles per stage summed over waves {refill, start, traverse,
                                  shade}, then {rounds, lanes} of start / traverse / shade */
     double kernel_ms;         /* HIP-event time of the render kernel on its stream (rtc_render only) */
@@ -159,12 +176,27 @@ int rtc_scene_add_triangles(rtc_scene *scene, size_t n, const double *points, co
  * camera/shape/group/pattern transform has det == 0.0 (the reference raises it lazily on the first ray that
  * touches the matrix, matrix.rs:157-161; every shape is touched by every ray). */
 int rtc_scene_commit(rtc_scene *scene, int device);
+/* The same for a single process that drives several GPUs (the reference's counterpart is the rayon
+ * loop over rows, camera.rs:72-85, plus the serial copy into the Canvas, :87-91): the scene is replicated on every
+ * listed device; rtc_render then shards a frame by interleaved 8-row tiles (tile t -> devices[t % n]), assembles the
+ * canvas on devices[0] with one peer copy per tile over xGMI and hands it to the host once.  rtc_render_device,
+ * rtc_render_device_static and explicit tile options keep using devices[0] only.  A device may be listed more than
+ * once (a rehearsal of the sharded path on a one-GPU box). */
+int rtc_scene_commit_devices(rtc_scene *scene, const int *devices, uint32_t n_devices);
 
 /* ---- the hot path: replaces Camera::render (camera.rs:64-93) ----
  * rgb_out: vsize*hsize*3 doubles, row-major canvas; like the reference, the last row and the last column
  * are never rendered and stay black (camera.rs:72,78).  Synchronous.  With tiling options only this rank's
  * rows are written (the rest of rgb_out is zeroed). */
 int rtc_render(rtc_scene *scene, const rtc_render_opts *opts, double *rgb_out, rtc_stats *stats);
+/* Errors of the render entry points beyond argument checks: RTC_ERR_OVERFLOW when a lane exceeded one of the
+ * kernel's per-lane bounds (max_rays_per_pixel, pending refractions, traversal stack): rtc_render reports it itself
+ * (the canvas is still written; the pixels concerned are NaN); after the asynchronous rtc_render_device ask
+ * rtc_scene_check().  The calls leave the caller's current HIP device as they found it. */
+
+/* Synchronises the scene's device and reports the state of the most recent launch on this scene: RTC_OK,
+ * RTC_ERR_OVERFLOW (see above) or RTC_ERR_HIP (the kernel faulted). */
+int rtc_scene_check(rtc_scene *scene);
 
 /* Device-resident variant for callers that own device memory and a stream (torch, RCCL pipelines):
  * d_rgb is a DEVICE pointer to rtc_local_rows(...)*hsize*3 doubles; this rank's rows are stored compactly in
@@ -184,7 +216,9 @@ typedef struct rtc_scene_info {
     uint32_t n_prims, n_unbounded, n_bvh_nodes, n_xforms, n_materials, n_lights, n_patterns, n_triangles;
     uint32_t bvh_max_depth, bvh_max_leaf;
     uint32_t committed, device;
-    uint64_t device_bytes;
+    uint64_t device_bytes; /* all replicas */
+    uint32_t n_devices;    /* replicas (rtc_scene_commit_devices) */
+    uint32_t pad;
 } rtc_scene_info;
 int rtc_scene_get_info(rtc_scene *scene, rtc_scene_info *out);
 

@@ -52,7 +52,10 @@ class RenderOpts(C.Structure):
         ("use_bvh", C.c_uint32),
         ("collect_stats", C.c_uint32),
         ("schedule", C.c_uint32),
-        ("reserved", C.c_uint32 * 1),
+        ("exchange", C.c_uint32),
+        ("max_rays_per_pixel", C.c_uint32),
+        ("fp_mode", C.c_uint32),
+        ("reserved", C.c_uint32 * 6),
     ]
 
 
@@ -72,6 +75,7 @@ class Stats(C.Structure):
         ("schlick_evals", C.c_uint64),
         ("refract_evals", C.c_uint64),
         ("overflow", C.c_uint64),
+        ("shadow_rays_skipped", C.c_uint64),
         ("diag", C.c_uint64 * 10),
         ("kernel_ms", C.c_double),
         ("algorithmic_flops", C.c_double),
@@ -89,7 +93,7 @@ class SceneInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "hsize", "vsize", "n_prims", "n_unbounded", "n_bvh_nodes", "n_xforms", "n_materials", "n_lights",
         "n_patterns", "n_triangles", "bvh_max_depth", "bvh_max_leaf", "committed", "device")] + [
-        ("device_bytes", C.c_uint64)]
+        ("device_bytes", C.c_uint64), ("n_devices", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class ItemInfo(C.Structure):
@@ -137,6 +141,8 @@ SYMBOLS = [
     ("rtc_scene_add_shape", C.c_int, [C.c_void_p, C.c_int, PD, C.c_uint32, C.c_double, C.c_double, C.c_int]),
     ("rtc_scene_add_triangles", C.c_int, [C.c_void_p, C.c_size_t, PD, PD, C.c_uint32]),
     ("rtc_scene_commit", C.c_int, [C.c_void_p, C.c_int]),
+    ("rtc_scene_commit_devices", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_uint32]),
+    ("rtc_scene_check", C.c_int, [C.c_void_p]),
     ("rtc_render", C.c_int, [C.c_void_p, C.POINTER(RenderOpts), PD, C.POINTER(Stats)]),
     ("rtc_render_device", C.c_int, [C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]),
     ("rtc_local_rows", C.c_uint32, [C.c_uint32] * 4),

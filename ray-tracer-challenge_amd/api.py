@@ -293,7 +293,8 @@ class World:
 class CompiledScene:
     """An rtc_scene handle: World + Camera pushed through the C ABI and committed to one GPU."""
 
-    def __init__(self, world: World, camera: "Camera", device: int = 0):
+    def __init__(self, world: World, camera: "Camera", device=0):
+        """device: one HIP device index, or a list of them (rtc_scene_commit_devices: one process, several GPUs)"""
         self.L = N.lib()
         self.h = C.c_void_p(self.L.rtc_scene_create())
         if not self.h:
@@ -313,7 +314,12 @@ class CompiledScene:
                 N.check(L.rtc_scene_add_point_light(h, _d3(light.position), _d3(light.intensity)))
         for obj in world.objects:
             self._add(obj)
-        N.check(L.rtc_scene_commit(h, device))
+        if isinstance(device, (list, tuple)):
+            arr = (C.c_int * len(device))(*device)
+            N.check(L.rtc_scene_commit_devices(h, arr, len(device)))
+            device = device[0]
+        else:
+            N.check(L.rtc_scene_commit(h, device))
         self.device = device
 
     def close(self):
@@ -388,22 +394,31 @@ class CompiledScene:
             raise TypeError(f"unsupported object {type(obj)}")
 
     # ---- rendering ----
-    def _opts(self, depth=5, tile_rows=0, tile_index=0, tile_count=1, use_bvh=0, collect_stats=False, schedule=0):
+    def _opts(self, depth=5, tile_rows=0, tile_index=0, tile_count=1, use_bvh=0, collect_stats=False, schedule=0,
+              exchange=0, max_rays_per_pixel=0, fp_mode=0):
         o = N.RenderOpts()
         self.L.rtc_render_opts_default(C.byref(o))
         o.depth, o.tile_rows, o.tile_index, o.tile_count = depth, tile_rows, tile_index, tile_count
         o.use_bvh, o.collect_stats = use_bvh, 1 if collect_stats else 0
-        o.schedule = schedule
+        o.schedule, o.exchange, o.max_rays_per_pixel, o.fp_mode = schedule, exchange, max_rays_per_pixel, fp_mode
         return o
 
-    def render(self, **kw):
-        """rtc_render: full canvas as a (vsize, hsize, 3) float64 numpy array + stats dict."""
+    def render(self, out=None, **kw):
+        """rtc_render: full canvas as a (vsize, hsize, 3) float64 numpy array + stats dict.  RTC_ERR_OVERFLOW raises
+        RtcError; the canvas written so far is kept in `last_canvas`."""
         o = self._opts(**kw)
-        out = np.zeros((self.vsize, self.hsize, 3), dtype=np.float64)
+        if out is None:
+            out = np.zeros((self.vsize, self.hsize, 3), dtype=np.float64)
         st = N.Stats()
-        N.check(self.L.rtc_render(self.h, C.byref(o), out.ctypes.data_as(N.PD), C.byref(st)))
+        self.last_canvas = out
+        rc = self.L.rtc_render(self.h, C.byref(o), out.ctypes.data_as(N.PD), C.byref(st))
         self.last_stats = st.as_dict()
+        N.check(rc)
         return out
+
+    def check(self):
+        """rtc_scene_check: synchronise and report the most recent launch (raises RtcError on overflow / fault)"""
+        N.check(self.L.rtc_scene_check(self.h))
 
     def local_rows(self, tile_rows=0, tile_index=0, tile_count=1):
         return int(self.L.rtc_local_rows(self.vsize, tile_rows, tile_index, tile_count))
@@ -467,8 +482,13 @@ class NativeScene(CompiledScene):
         N.check(L.rtc_scene_add_obj(sc.h, text.encode(), t, material_id, C.byref(info)))
         return sc, {n: getattr(info, n) for n, _ in info._fields_}
 
-    def commit(self, device: int = 0):
-        N.check(self.L.rtc_scene_commit(self.h, device))
+    def commit(self, device=0):
+        if isinstance(device, (list, tuple)):
+            arr = (C.c_int * len(device))(*device)
+            N.check(self.L.rtc_scene_commit_devices(self.h, arr, len(device)))
+            device = device[0]
+        else:
+            N.check(self.L.rtc_scene_commit(self.h, device))
         self.device = device
         return self
 

@@ -2,8 +2,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <vector>
 
@@ -22,7 +24,7 @@ struct rtc_scene {
 extern "C" {
 
 const char *rtc_last_error(void) { return rtc::last_error(); }
-const char *rtc_version(void) { return "rtc_amd 0.1 (gfx950, strict fp64)"; }
+const char *rtc_version(void) { return "rtc_amd 0.2 (gfx950; fp64, strict and fast flavours)"; }
 
 void rtc_material_default(rtc_material *m) {
     // material.rs:83-96
@@ -212,7 +214,16 @@ int rtc_scene_add_triangles(rtc_scene *scene, size_t n, const double *points, co
 
 int rtc_scene_commit(rtc_scene *scene, int device) {
     CHECK_SCENE(scene)
-    return scene->s.commit(device);
+    return scene->s.commit(&device, 1);
+}
+
+int rtc_scene_commit_devices(rtc_scene *scene, const int *devices, uint32_t n_devices) {
+    CHECK_SCENE(scene)
+    if (!devices || n_devices == 0 || n_devices > RTC_MAX_DEVICES) {
+        set_error("device list must hold 1..%d entries", RTC_MAX_DEVICES);
+        return RTC_ERR_INVALID;
+    }
+    return scene->s.commit(devices, n_devices);
 }
 
 // ---- render ----------------------------------------------------------------------------------
@@ -240,7 +251,7 @@ static int resolve_params(Scene &s, const rtc_render_opts *opts_in, DRenderParam
         o = *opts_in;
     else
         rtc_render_opts_default(&o);
-    if (!s.committed || s.device < 0) {
+    if (!s.committed || s.device < 0 || s.reps.empty()) {
         set_error("scene is not committed to a HIP device; librtc_amd renders on the GPU only");
         return s.committed ? RTC_ERR_NO_DEVICE : RTC_ERR_STATE;
     }
@@ -256,8 +267,13 @@ static int resolve_params(Scene &s, const rtc_render_opts *opts_in, DRenderParam
         }
         o.tile_rows = s.vsize;
     }
-    if (o.depth > 64) {
-        set_error("depth %u exceeds the supported bounce budget (64)", o.depth);
+    // the explicit per-lane stack holds one pending refraction per distinct `remaining` value
+    if (o.depth > 8) {
+        set_error("depth %u exceeds the per-lane stack of waiting refracted rays (8)", o.depth);
+        return RTC_ERR_INVALID;
+    }
+    if (o.fp_mode > 1) {
+        set_error("fp_mode %u: 0 = strict, 1 = fast", o.fp_mode);
         return RTC_ERR_INVALID;
     }
     p = DRenderParams{};
@@ -269,11 +285,14 @@ static int resolve_params(Scene &s, const rtc_render_opts *opts_in, DRenderParam
     p.use_bvh = (o.use_bvh == 1) ? 1u : (o.use_bvh == 2) ? 0u : (bounded > 4 ? 1u : 0u);
     // auto: deep ray trees come from transparent surfaces (refraction keeps the bounce budget, world.rs:142)
     p.persistent = (o.schedule == 2) ? 1u : (o.schedule == 1) ? 0u : (s.n_transparent_prims > 64 ? 1u : 0u);
+    p.share = (o.exchange == 1) ? 0u : 1u;
+    p.max_rays = o.max_rays_per_pixel;
+    p.fast = o.fp_mode;
     p.tiles_x = (s.hsize + 7u) / 8u;
     p.tiles_y = (p.local_rows + 7u) / 8u;
-    // the explicit per-lane stack holds one pending refraction per distinct `remaining` value
-    if (o.depth > 8) {
-        set_error("depth %u exceeds the per-lane pending stack (8)", o.depth);
+    // a lane's pixel is tile * 64 + position in 32 bits
+    if ((uint64_t)p.tiles_x * p.tiles_y >= (1ull << 26)) {
+        set_error("%u x %u pixels: a launch covers at most 2^26 8x8 tiles", s.hsize, p.local_rows);
         return RTC_ERR_INVALID;
     }
     return RTC_OK;
@@ -282,6 +301,7 @@ static int resolve_params(Scene &s, const rtc_render_opts *opts_in, DRenderParam
 static void fill_stats(Scene &s, const std::vector<uint64_t> &c, rtc_stats &st) {
     st.primary_rays = c[ST_PRIMARY];
     st.shadow_rays = c[ST_SHADOW];
+    st.shadow_rays_skipped = c[ST_SHADOW_SKIPPED];
     st.secondary_rays = c[ST_SECONDARY];
     st.secondary_rays_reference = c[ST_SECONDARY_REF];
     st.container_passes = c[ST_CONTAINER];
@@ -306,11 +326,47 @@ static void fill_stats(Scene &s, const std::vector<uint64_t> &c, rtc_stats &st) 
         if (ncone > 0) cone = 32 + 18 * (ncone_closed / ncone);
     }
     const double per_type[7] = {27, 1, 12, cyl, cone, 46, 46};
+    // a skipped shadow query still forms its ray (18 flops, world.rs:79-81): that is how the kernel learns that the
+    // light is behind the surface
     double f = 33.0 * (double)st.xform_levels + 12.0 * (double)st.box_tests + 79.0 * (double)st.shaded_hits +
-               67.0 * (double)st.light_evals + 18.0 * (double)st.shadow_rays + 25.0 * (double)st.schlick_evals +
-               26.0 * (double)st.refract_evals;
+               67.0 * (double)st.light_evals + 18.0 * (double)(st.shadow_rays + st.shadow_rays_skipped) +
+               25.0 * (double)st.schlick_evals + 26.0 * (double)st.refract_evals;
     for (int i = 0; i < 7; i++) f += per_type[i] * (double)st.prim_tests[i];
     st.algorithmic_flops = f;
+}
+
+// one asynchronous launch on replica r with `work` as the grid's work buffer
+static int launch_on(Scene &s, DeviceReplica &r, const DRenderParams &p, const rtc_render_opts &o, double *d_rgb,
+                     unsigned *work, hipStream_t st, bool refuse_oversize = false) {
+    if (o.collect_stats) {
+        if (hipMemsetAsync(r.d_stats, 0, sizeof(uint64_t) * ST_COUNT, st) != hipSuccess) {
+            set_error("hipMemsetAsync(stats) failed");
+            return RTC_ERR_HIP;
+        }
+        s.have_last_stats = true;
+    }
+    r.last_work = work;
+    return (p.fast ? fastfp::launch_render : launch_render)(r.dscene, p, d_rgb, r.d_stats, work, r.n_cu,
+                                                            o.collect_stats != 0, st, &r.last_launch_id, refuse_oversize);
+}
+
+// Did a lane of replica r's most recent launch exceed a per-lane bound?  (the device must be idle)
+static int read_overflow(DeviceReplica &r, bool &overflow) {
+    overflow = false;
+    if (!r.last_work || r.last_launch_id == 0) return RTC_OK;
+    uint32_t flag = 0;
+    if (hipMemcpy(&flag, r.last_work + RTC_WORK_FLAG, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("hipMemcpy(overflow flag) failed: %s", hipGetErrorString(hipGetLastError()));
+        return RTC_ERR_HIP;
+    }
+    overflow = flag == r.last_launch_id;
+    return RTC_OK;
+}
+
+static int overflow_error() {
+    set_error("a lane exceeded a per-lane bound of the kernel (rays per pixel, waiting refracted rays or traversal "
+              "stack): the pixels concerned are NaN");
+    return RTC_ERR_OVERFLOW;
 }
 
 int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream) {
@@ -324,50 +380,128 @@ int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_r
         set_error("d_rgb is NULL");
         return RTC_ERR_INVALID;
     }
+    DeviceReplica &r = s.reps[0];
+    unsigned *work = r.d_work;
     if (p.local_rows == 0) return RTC_OK;
-    int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess || cur != s.device) {
-        if (hipSetDevice(s.device) != hipSuccess) {
-            set_error("hipSetDevice(%d) failed", s.device);
+    DeviceGuard guard(r.device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", r.device);
+        return RTC_ERR_HIP;
+    }
+    return launch_on(s, r, p, o, d_rgb, work, (hipStream_t)hip_stream);
+}
+
+int rtc_scene_check(rtc_scene *scene) {
+    CHECK_SCENE(scene)
+    Scene &s = scene->s;
+    if (!s.committed || s.device < 0 || s.reps.empty()) {
+        set_error("scene is not committed to a device");
+        return RTC_ERR_STATE;
+    }
+    bool any = false;
+    for (DeviceReplica &r : s.reps) {
+        DeviceGuard guard(r.device);
+        if (hipDeviceSynchronize() != hipSuccess) {
+            set_error("hipDeviceSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
             return RTC_ERR_HIP;
         }
+        bool ov = false;
+        if (int rc = read_overflow(r, ov)) return rc;
+        any = any || ov;
     }
-    if (o.collect_stats) {
-        if (hipMemsetAsync(s.d_stats, 0, sizeof(uint64_t) * ST_COUNT, (hipStream_t)hip_stream) != hipSuccess) {
-            set_error("hipMemsetAsync(stats) failed");
-            return RTC_ERR_HIP;
-        }
-        s.have_last_stats = true;
-        std::memset(&s.last_stats, 0, sizeof s.last_stats);
-        s.last_stats.pixels = (uint64_t)(s.hsize - 1) * 0;  // filled by rtc_scene_last_stats
-    }
-    return launch_render(s.dscene, p, d_rgb, s.d_stats, s.d_work, s.max_waves, o.collect_stats != 0, hip_stream);
+    return any ? overflow_error() : RTC_OK;
 }
 
 int rtc_scene_last_stats(rtc_scene *scene, rtc_stats *stats) {
     CHECK_SCENE(scene)
     Scene &s = scene->s;
-    if (!s.committed || s.device < 0 || !s.d_stats) {
+    if (!s.committed || s.device < 0 || s.reps.empty()) {
         set_error("scene is not committed to a device");
         return RTC_ERR_STATE;
     }
     if (!stats) return RTC_ERR_INVALID;
-    (void)hipSetDevice(s.device);
-    if (hipDeviceSynchronize() != hipSuccess) {
-        set_error("hipDeviceSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
-        return RTC_ERR_HIP;
-    }
-    std::vector<uint64_t> c(ST_COUNT, 0);
-    if (hipMemcpy(c.data(), s.d_stats, sizeof(uint64_t) * ST_COUNT, hipMemcpyDeviceToHost) != hipSuccess) {
-        set_error("hipMemcpy(stats) failed");
-        return RTC_ERR_HIP;
+    std::vector<uint64_t> total(ST_COUNT, 0), c(ST_COUNT, 0);
+    bool overflow = false;
+    for (DeviceReplica &r : s.reps) {
+        DeviceGuard guard(r.device);
+        if (hipDeviceSynchronize() != hipSuccess) {
+            set_error("hipDeviceSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
+            return RTC_ERR_HIP;
+        }
+        if (hipMemcpy(c.data(), r.d_stats, sizeof(uint64_t) * ST_COUNT, hipMemcpyDeviceToHost) != hipSuccess) {
+            set_error("hipMemcpy(stats) failed");
+            return RTC_ERR_HIP;
+        }
+        for (int i = 0; i < ST_COUNT; i++) total[i] += c[i];
+        bool ov = false;
+        if (int rc = read_overflow(r, ov)) return rc;
+        overflow = overflow || ov;
     }
     rtc_stats st{};
-    fill_stats(s, c, st);
+    fill_stats(s, total, st);
     st.pixels = st.primary_rays;
     st.kernel_ms = s.last_stats.kernel_ms;
     *stats = st;
-    return st.overflow ? RTC_ERR_OVERFLOW : RTC_OK;
+    return (st.overflow || overflow) ? overflow_error() : RTC_OK;
+}
+
+// Device-to-host copy of `bytes` through the scene's two pinned staging buffers: chunk k+1 crosses PCIe while
+// chunk k is copied out of its staging buffer.  place(offset, src, n) stores n bytes that start `offset` bytes into
+// the device buffer.
+typedef std::function<void(size_t, const char *, size_t)> Place;
+static int staged_download(Scene &s, const char *d_src, size_t bytes, hipStream_t st, const Place &place) {
+    const size_t CHUNK = (size_t)16 << 20;
+    if (!s.h_stage[0]) {
+        for (void *&h : s.h_stage)
+            if (hipHostMalloc(&h, CHUNK, hipHostMallocDefault) != hipSuccess) {
+                set_error("hipHostMalloc(%zu) for the staging buffer failed", CHUNK);
+                return RTC_ERR_HIP;
+            }
+        s.stage_bytes = CHUNK;
+    }
+    hipEvent_t ev[2];
+    for (hipEvent_t &e : ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            set_error("hipEventCreate failed");
+            return RTC_ERR_HIP;
+        }
+    int rc = RTC_OK;
+    const size_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
+    auto issue = [&](size_t k) {
+        const size_t off = k * CHUNK, n = std::min(CHUNK, bytes - off);
+        if (hipMemcpyAsync(s.h_stage[k & 1], d_src + off, n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipEventRecord(ev[k & 1], st) != hipSuccess) {
+            set_error("device-to-host copy of the canvas failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = RTC_ERR_HIP;
+        }
+    };
+    if (n_chunks > 0) issue(0);
+    for (size_t k = 0; k < n_chunks && rc == RTC_OK; k++) {
+        if (k + 1 < n_chunks) issue(k + 1);
+        if (rc != RTC_OK) break;
+        if (hipEventSynchronize(ev[k & 1]) != hipSuccess) {
+            set_error("device-to-host copy of the canvas failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = RTC_ERR_HIP;
+            break;
+        }
+        const size_t off = k * CHUNK;
+        place(off, (const char *)s.h_stage[k & 1], std::min(CHUNK, bytes - off));
+    }
+    if (rc != RTC_OK) (void)hipStreamSynchronize(st);  // nothing may still write the staging buffers
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+static int ensure_canvas(DeviceReplica &r, size_t bytes) {
+    if (r.canvas_bytes >= bytes) return RTC_OK;
+    if (r.d_canvas) (void)hipFree(r.d_canvas);
+    r.d_canvas = nullptr, r.canvas_bytes = 0;
+    if (hipMalloc((void **)&r.d_canvas, bytes) != hipSuccess) {
+        set_error("hipMalloc(%zu) for the canvas failed", bytes);
+        return RTC_ERR_HIP;
+    }
+    r.canvas_bytes = bytes;
+    return RTC_OK;
 }
 
 int rtc_render(rtc_scene *scene, const rtc_render_opts *opts, double *rgb_out, rtc_stats *stats) {
@@ -381,58 +515,117 @@ int rtc_render(rtc_scene *scene, const rtc_render_opts *opts, double *rgb_out, r
         set_error("rgb_out is NULL");
         return RTC_ERR_INVALID;
     }
-    if (hipSetDevice(s.device) != hipSuccess) {
-        set_error("hipSetDevice(%d) failed", s.device);
-        return RTC_ERR_HIP;
-    }
-    const size_t row_doubles = (size_t)s.hsize * 3;
-    std::memset(rgb_out, 0, sizeof(double) * row_doubles * s.vsize);  // Canvas::new: all black (canvas.rs:14-29)
+    const size_t row_doubles = (size_t)s.hsize * 3, row_bytes = row_doubles * sizeof(double);
+    const uint32_t n_rep = (uint32_t)s.reps.size();
+    const bool multi = n_rep > 1 && o.tile_count == 1;
     if (stats) std::memset(stats, 0, sizeof *stats);
+    // Canvas::new: all black (canvas.rs:14-29).  A whole-frame render writes every row, a tiled one only its own.
+    if (o.tile_count > 1) std::memset(rgb_out, 0, row_bytes * s.vsize);
     if (p.local_rows == 0) return RTC_OK;
-    double *d_rgb = nullptr;
-    const size_t bytes = sizeof(double) * row_doubles * p.local_rows;
-    if (hipMalloc((void **)&d_rgb, bytes) != hipSuccess) {
-        set_error("hipMalloc(%zu) for the canvas failed", bytes);
+    DeviceReplica &r0 = s.reps[0];
+    DeviceGuard guard(r0.device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", r0.device);
         return RTC_ERR_HIP;
-    }
-    hipStream_t st = nullptr;
-    if (o.collect_stats) (void)hipMemsetAsync(s.d_stats, 0, sizeof(uint64_t) * ST_COUNT, st);
-    (void)hipEventRecord((hipEvent_t)s.ev_start, st);
-    rc = launch_render(s.dscene, p, d_rgb, s.d_stats, s.d_work, s.max_waves, o.collect_stats != 0, st);
-    (void)hipEventRecord((hipEvent_t)s.ev_stop, st);
-    if (rc == RTC_OK) {
-        const hipError_t e = hipEventSynchronize((hipEvent_t)s.ev_stop);
-        if (e != hipSuccess) {
-            set_error("render kernel failed: %s", hipGetErrorString(e));
-            rc = RTC_ERR_HIP;
-        }
     }
     float ms = 0.f;
-    if (rc == RTC_OK) (void)hipEventElapsedTime(&ms, (hipEvent_t)s.ev_start, (hipEvent_t)s.ev_stop);
-    s.last_stats.kernel_ms = ms;
-    if (rc == RTC_OK) {
-        std::vector<double> host(row_doubles * p.local_rows);
-        if (hipMemcpy(host.data(), d_rgb, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
-            set_error("hipMemcpy D2H of the canvas failed");
-            rc = RTC_ERR_HIP;
+    if (!multi) {
+        const size_t bytes = row_bytes * p.local_rows;
+        if ((rc = ensure_canvas(r0, bytes))) return rc;
+        hipStream_t st = nullptr;
+        (void)hipEventRecord((hipEvent_t)r0.ev_start, st);
+        rc = launch_on(s, r0, p, o, r0.d_canvas, r0.d_work, st);
+        (void)hipEventRecord((hipEvent_t)r0.ev_stop, st);
+        if (rc) return rc;
+        if (o.tile_count == 1) {
+            rc = staged_download(s, (const char *)r0.d_canvas, bytes, st,
+                                 [&](size_t off, const char *src, size_t n) { std::memcpy((char *)rgb_out + off, src, n); });
         } else {
             std::vector<uint32_t> rows(p.local_rows);
             rtc_local_row_map(s.vsize, o.tile_rows, o.tile_index, o.tile_count, rows.data(), p.local_rows);
-            for (uint32_t l = 0; l < p.local_rows; l++)
-                std::memcpy(rgb_out + (size_t)rows[l] * row_doubles, host.data() + (size_t)l * row_doubles,
-                            sizeof(double) * row_doubles);
+            rc = staged_download(s, (const char *)r0.d_canvas, bytes, st, [&](size_t off, const char *src, size_t n) {
+                while (n > 0) {  // a chunk holds parts of several compact rows
+                    const size_t l = off / row_bytes, in_row = off - l * row_bytes, m = std::min(n, row_bytes - in_row);
+                    std::memcpy((char *)rgb_out + (size_t)rows[l] * row_bytes + in_row, src, m);
+                    off += m, src += m, n -= m;
+                }
+            });
         }
+        if (rc) return rc;
+        if (hipEventSynchronize((hipEvent_t)r0.ev_stop) != hipSuccess) {
+            set_error("render kernel failed: %s", hipGetErrorString(hipGetLastError()));
+            return RTC_ERR_HIP;
+        }
+        (void)hipEventElapsedTime(&ms, (hipEvent_t)r0.ev_start, (hipEvent_t)r0.ev_stop);
+    } else {
+        // ---- one process, several GPUs (camera.rs:72-91): replica k renders the interleaved 8-row
+        // tiles t % N == k into a compact buffer on its own device and stream; each buffer then moves into the
+        // canvas on the primary device with ONE strided device-to-device copy over its xGMI link (7 peers = 7
+        // distinct links into device 0; no ring, no reduction), and the canvas goes to the host once. ----
+        const uint32_t TILE = 8;
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<DRenderParams> ps(n_rep);
+        std::vector<rtc_render_opts> os(n_rep);
+        for (uint32_t k = 0; k < n_rep; k++) {
+            rtc_render_opts ok = o;
+            ok.tile_rows = TILE, ok.tile_index = k, ok.tile_count = n_rep;
+            if ((rc = resolve_params(s, &ok, ps[k], os[k]))) return rc;
+        }
+        // the canvas lives on the primary device; replica 0's compact buffer sits behind it
+        if ((rc = ensure_canvas(r0, row_bytes * (s.vsize + (size_t)ps[0].local_rows)))) return rc;
+        auto compact = [&](uint32_t k) { return k == 0 ? r0.d_canvas + row_doubles * s.vsize : s.reps[k].d_canvas; };
+        for (uint32_t k = 0; k < n_rep && rc == RTC_OK; k++) {
+            DeviceReplica &r = s.reps[k];
+            if (ps[k].local_rows == 0) continue;
+            DeviceGuard g(r.device);
+            if (k > 0 && (rc = ensure_canvas(r, row_bytes * ps[k].local_rows))) break;
+            rc = launch_on(s, r, ps[k], os[k], compact(k), r.d_work, (hipStream_t)r.stream);
+        }
+        for (uint32_t k = 0; k < n_rep && rc == RTC_OK; k++) {
+            DeviceReplica &r = s.reps[k];
+            DeviceGuard g(r.device);
+            // compact tile j of replica k is canvas tile j * N + k; one peer copy per tile, on the replica's stream
+            const size_t tile_bytes = row_bytes * TILE;
+            for (uint32_t done = 0, j = 0; done < ps[k].local_rows && rc == RTC_OK; done += TILE, j++) {
+                const uint32_t rows = std::min(TILE, ps[k].local_rows - done);
+                char *dst = (char *)r0.d_canvas + ((size_t)j * n_rep + k) * tile_bytes;
+                const char *src = (const char *)compact(k) + (size_t)j * tile_bytes;
+                const hipError_t e = hipMemcpyPeerAsync(dst, r0.device, src, r.device, row_bytes * rows, (hipStream_t)r.stream);
+                if (e != hipSuccess) {
+                    set_error("device-to-device copy of replica %u's tiles failed: %s", k, hipGetErrorString(e));
+                    rc = RTC_ERR_HIP;
+                }
+            }
+        }
+        for (uint32_t k = 0; k < n_rep; k++) {
+            DeviceGuard g(s.reps[k].device);
+            if (hipStreamSynchronize((hipStream_t)s.reps[k].stream) != hipSuccess && rc == RTC_OK) {
+                set_error("replica %u failed: %s", k, hipGetErrorString(hipGetLastError()));
+                rc = RTC_ERR_HIP;
+            }
+        }
+        if (rc) return rc;
+        ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        rc = staged_download(s, (const char *)r0.d_canvas, row_bytes * s.vsize, nullptr,
+                             [&](size_t off, const char *src, size_t n) { std::memcpy((char *)rgb_out + off, src, n); });
+        if (rc) return rc;
     }
-    (void)hipFree(d_rgb);
-    if (rc == RTC_OK && stats) {
+    s.last_stats.kernel_ms = ms;
+    bool overflow = false;
+    for (uint32_t k = 0; k < (multi ? n_rep : 1u); k++) {
+        DeviceGuard g(s.reps[k].device);
+        bool ov = false;
+        if ((rc = read_overflow(s.reps[k], ov))) return rc;
+        overflow = overflow || ov;
+    }
+    if (stats) {
         if (o.collect_stats) {
-            s.have_last_stats = true;
             rc = rtc_scene_last_stats(scene, stats);
-        } else {
-            stats->kernel_ms = ms;
+            if (rc && rc != RTC_ERR_OVERFLOW) return rc;
         }
+        stats->kernel_ms = ms;
     }
-    return rc;
+    return overflow ? overflow_error() : RTC_OK;
 }
 
 int rtc_scene_get_info(rtc_scene *scene, rtc_scene_info *out) {
@@ -453,6 +646,7 @@ int rtc_scene_get_info(rtc_scene *scene, rtc_scene_info *out) {
     out->committed = s.committed ? 1 : 0;
     out->device = (uint32_t)s.device;
     out->device_bytes = s.device_bytes;
+    out->n_devices = (uint32_t)s.reps.size();
     return RTC_OK;
 }
 

@@ -28,7 +28,18 @@
 #include "rtc_scene.h"
 #include "rtc_types.h"
 
+// The file is compiled twice (Makefile): strict (-ffp-contract=off, rtc::launch_render: the parity flavour) and fast
+// (-ffp-contract=fast -DRTC_FAST, rtc::fastfp::launch_render: FMA contraction and shared reciprocals allowed).
+#ifdef RTC_FAST
+#define RTC_FLAVOUR_BEGIN namespace fastfp {
+#define RTC_FLAVOUR_END }
+#else
+#define RTC_FLAVOUR_BEGIN
+#define RTC_FLAVOUR_END
+#endif
+
 namespace rtc {
+RTC_FLAVOUR_BEGIN
 
 #define RTC_EPS 1e-5  // lib.rs:24
 #define RTC_WAVE 64
@@ -85,7 +96,21 @@ DEV V3 cross(V3 a, V3 b) {                                               // tupl
 DEV double magnitude(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // tuple.rs:96-99
 DEV V3 normalize(V3 a) {  // tuple.rs:101-108: three divisions
     const double m = magnitude(a);
+#ifdef RTC_FAST
+    const double r = 1. / m;  // fast flavour: one division shared by the three components
+    return mk(a.x * r, a.y * r, a.z * r);
+#else
     return mk(a.x / m, a.y / m, a.z / m);
+#endif
+}
+// the two roots (-b -+ sq) / (2a) of the quadrics (shape.rs:231-234, 917-918, 1238-1239)
+DEV void quadric_roots(double a, double b, double sq, double &t0, double &t1) {
+#ifdef RTC_FAST
+    const double r = 1. / (2. * a);  // fast flavour: one division for both roots
+    t0 = (-b - sq) * r, t1 = (-b + sq) * r;
+#else
+    t0 = (-b - sq) / (2. * a), t1 = (-b + sq) / (2. * a);
+#endif
 }
 DEV V3 reflect(V3 v, V3 n) {  // tuple.rs:122-124: self - (normal * 2.) * self.dot(normal)
     const double d = dot(v, n);
@@ -215,8 +240,10 @@ DEV void isect_sphere(const Ray &r, Trace &T, int pi) {
     const double disc = b * b - 4. * a * c;
     if (disc < 0.) return;
     const double sq = sqrt(disc);
-    visit(T, pi, (-b - sq) / (2. * a));
-    visit(T, pi, (-b + sq) / (2. * a));
+    double t0, t1;
+    quadric_roots(a, b, sq, t0, t1);
+    visit(T, pi, t0);
+    visit(T, pi, t1);
 }
 
 // shape.rs:708-720 (Q9: divides by a zero direction on purpose)
@@ -262,8 +289,8 @@ DEV void isect_cylinder(const Ray &r, double minimum, double maximum, int closed
         const double disc = b * b - 4. * a * c;
         if (disc < 0.) return;  // Q10: caps are not tested either
         const double sq = sqrt(disc);
-        double t0 = (-b - sq) / (2. * a);
-        double t1 = (-b + sq) / (2. * a);
+        double t0, t1;
+        quadric_roots(a, b, sq, t0, t1);
         if (t0 > t1) {
             const double t = t0;
             t0 = t1;
@@ -296,8 +323,8 @@ DEV void isect_cone(const Ray &r, double minimum, double maximum, int closed, Tr
         const double disc = b * b - 4. * a * c;
         if (disc < 0.) return;
         const double sq = sqrt(disc);
-        double t0 = (-b - sq) / (2. * a);
-        double t1 = (-b + sq) / (2. * a);
+        double t0, t1;
+        quadric_roots(a, b, sq, t0, t1);
         if (t0 > t1) {
             const double t = t0;
             t0 = t1;
@@ -513,6 +540,54 @@ DEV bool slab(const F *bmin, const F *bmax, const V3 &inv_d, const V3 &oi, doubl
     tnear = tn;
     return tn <= tf;
 }
+// ---- the traversal's own slab test, in f32 (RTC_SLAB_F64 keeps the f64 form of round 1 for A/B) ----
+// Box planes are exact in f32 (16-bit cell indices, or f32 planes); what is rounded is the ray's slope a = 1/d (times
+// the cell size) and intercept b = (origin of the frame - ray origin)/d, each once from their f64 values, and the
+// fma itself: |error of t| <= 2^-23 (qmax |a| + |b|) for every plane of the scene.  That bound e is folded into the
+// intercepts once per ray -- the plane that is NEAR for this ray's direction gets b - e, the far one b + e -- so the
+// test below is conservative without a single extra instruction: it may visit a box the exact test would skip (by
+// ~1e-6 relative, like the boxes' own padding), never the other way round.  The f64 pipe takes 4 cycles per wave
+// instruction and ONE wave saturates it; these f32 instructions take 2, the two planes of an axis share one
+// v_pk_fma_f32, and max3 / min3 fold three axes at once (tools/micro/valu_rates.hip has the measured rates).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct SlabRay {
+    float ax, ay, az;    // slope per axis
+    f32x2 bx, by, bz;    // intercepts of the (low, high) plane of an axis, widened by the error bound
+};
+DEV void slab_axis(double a64, double b64, double qmax, float &a, f32x2 &b) {
+    a = (float)a64;
+    const float bc = (float)b64;
+    const float e = ((float)qmax * fabsf(a) + fabsf(bc)) * 0x1p-21f;  // 4x the bound above
+    const float lo = bc - e, hi = bc + e;
+    b.x = (a >= 0.f) ? lo : hi;  // the low plane is the near one for a >= 0
+    b.y = (a >= 0.f) ? hi : lo;
+}
+// one box: (lo, hi) planes per axis; [lo_t, hi_t] is the ray segment of interest (already rounded outward)
+DEV bool slab32(f32x2 px, f32x2 py, f32x2 pz, const SlabRay &R, float lo_t, float hi_t, float &tnear) {
+    const f32x2 ax = {R.ax, R.ax}, ay = {R.ay, R.ay}, az = {R.az, R.az};
+    const f32x2 tx = __builtin_elementwise_fma(px, ax, R.bx);
+    const f32x2 ty = __builtin_elementwise_fma(py, ay, R.by);
+    const f32x2 tz = __builtin_elementwise_fma(pz, az, R.bz);
+    const float nx = __builtin_fminf(tx.x, tx.y), fx = __builtin_fmaxf(tx.x, tx.y);
+    const float ny = __builtin_fminf(ty.x, ty.y), fy = __builtin_fmaxf(ty.x, ty.y);
+    const float nz = __builtin_fminf(tz.x, tz.y), fz = __builtin_fmaxf(tz.x, tz.y);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), lo_t);
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx, fy), fz), hi_t);
+    tnear = tn;
+    return !(tn > tf);  // (a NaN -- coordinates beyond the range of f32 -- visits the box)
+}
+// the six planes of a quantised box: d0 = min.x | min.y << 16, d1 = min.z | max.x << 16, d2 = max.y | max.z << 16
+DEV bool slab32_q(unsigned d0, unsigned d1, unsigned d2, const SlabRay &R, float lo_t, float hi_t, float &tnear) {
+    const f32x2 px = {(float)(d0 & 0xffffu), (float)(d1 >> 16)};
+    const f32x2 py = {(float)(d0 >> 16), (float)(d2 & 0xffffu)};
+    const f32x2 pz = {(float)(d1 & 0xffffu), (float)(d2 >> 16)};
+    return slab32(px, py, pz, R, lo_t, hi_t, tnear);
+}
+// T.lim (> 0 or +inf) as the end of the f32 ray segment: rounded away from / towards zero
+DEV float f32_above(double x) { return (float)(x * (1. + 0x1p-22)); }
+DEV float f32_below(double x) { return (float)(x * (1. - 0x1p-22)); }
+
+#ifdef RTC_SLAB_F64
 // Quantised boxes: both children of a DBvhNodeQ against one ray.  The near / far plane of an axis is known from
 // the sign of the ray direction, so each plane index is picked out of the node's dwords by ONE v_perm_b32 with a
 // per-lane selector (extraction and near/far choice in a single instruction), and no min/max per axis is needed:
@@ -533,6 +608,7 @@ DEV bool slab_q(unsigned d0, unsigned d1, unsigned d2, unsigned sx, unsigned sy,
     tnear = tn;
     return tn <= tf;
 }
+#endif
 DEV double safe_rcp(double d) {
     const double r = __builtin_amdgcn_rcp(d);
     const double a = fmin(fabs(r), 1e30);  // d == 0 (or denormal): a huge finite slope keeps fma() NaN-free
@@ -584,6 +660,9 @@ DEV Ray through_ancestors(const DScene &s, int off, int len, Ray r) {
 // register-hungry pass: that is what lets RTC_MIN_WAVES waves share a SIMD.  PARK selects how much is parked.
 #ifndef RTC_LDS_STACK
 #define RTC_LDS_STACK 16
+#endif
+#ifndef RTC_LDS_TOP
+#define RTC_LDS_TOP 0
 #endif
 //  // BVH stack entries kept in LDS; deeper entries spill to a per-lane scratch array
 enum ParkSlot {
@@ -715,6 +794,15 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                                                                      unsigned *__restrict__ work) {
     __shared__ int bvh_stack[RTC_LDS_STACK * RTC_WAVE];
     __shared__ double parked[PK_COUNT * RTC_WAVE];
+#if RTC_LDS_TOP
+    // A/B only ("LDS staging"): the first RTC_LDS_TOP nodes of the breadth-first hierarchy -- its
+    // top levels -- copied into LDS by every wave.  LDS is what bounds the occupancy (12.8 KB per wave x 12 waves of the
+    // CU's 160 KB), so the copy has to be paid for with traversal-stack entries (build with a smaller RTC_LDS_STACK).
+    __shared__ uint4 top_nodes[RTC_LDS_TOP * 2];
+    const int n_top = QNODES ? (s.n_bvh_nodes < RTC_LDS_TOP ? s.n_bvh_nodes : RTC_LDS_TOP) : 0;
+    if (QNODES)
+        for (int i = (int)threadIdx.x; i < n_top * 2; i += RTC_WAVE) top_nodes[i] = ((const uint4 *)s.bvh_q)[i];
+#endif
     const unsigned lane = threadIdx.x;
     int *const stack = &bvh_stack[lane];  // [entry][lane]: conflict free
     lds_f64 *const pk = (lds_f64 *)parked + lane;
@@ -765,7 +853,13 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     // ---- BVH traversal state of the pass in flight (resumable) ----
     bool in_pass = false;
     int pos = 0, end = 0, sb = 0, cur = RTC_NO_NODE;
+#ifdef RTC_SLAB_F64
     V3 inv_d = mk(0., 0., 0.), oi = mk(0., 0., 0.);
+#else
+    SlabRay slab_ray;  // this pass's ray in the slab test's f32 form (persists with the traversal)
+    slab_ray.ax = slab_ray.ay = slab_ray.az = 0.f;
+    slab_ray.bx = slab_ray.by = slab_ray.bz = (f32x2){0.f, 0.f};
+#endif
     // The ray in group space is cached per lane across the leaves of a pass when primitives sit in groups.  The
     // persistent schedule is chosen for glass-heavy scenes, where the 13 registers this costs between passes are
     // worth more than the transform it saves: there the ray is transformed per grouped leaf.
@@ -865,6 +959,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         px[0] = 0., px[1] = 0., px[2] = 0.;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the stores are in L2 before any lane adds to them)
     };
+    // a per-lane bound was exceeded: the host finds this launch's id in the flag word and reports RTC_ERR_OVERFLOW
+    auto flag_overflow = [&]() { wb_store(work + RTC_WORK_FLAG, prm.launch_id); };
     if (PERSISTENT && prm.share && lane == 0) atomicAdd(work + RTC_WORK_BUSY, 1u);
     unsigned long long *const my_box =
         (unsigned long long *)((char *)work + RTC_WORK_MBOX_BYTES) + (size_t)blockIdx.x * 64u * RTC_MBOX_ITEM_U64;
@@ -957,7 +1053,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             // ---- tail: no tile is left.  A few pixels of the stress scene grow ray trees of 10^4 rays, which one lane
             // traces in ~0.3 s -- a sixth of the whole frame -- while its neighbours sit idle.  Free lanes therefore take
             // over the oldest waiting ray (the largest untraced subtree) of a busy lane of the same wave. ----
-            if (PERSISTENT && exhausted && r_next == r_end) {
+            // (prm.share == 0 turns BOTH hand-overs off: every pixel is then traced by one lane from start to end and the
+            // frame is bit-reproducible, like the static schedule's)
+            if (PERSISTENT && prm.share && exhausted && r_next == r_end) {
                 unsigned long long recv = __ballot(!alive);
                 unsigned long long don = __ballot(alive && sp > 0);
                 while (recv != 0ull && don != 0ull) {
@@ -988,7 +1086,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 // without work publishes its hunger, a wave with waiting rays claims one hungry wave per round
                 // (compare-and-swap on that wave's mailbox state) and moves its lanes' oldest waiting rays there. ----
                 const unsigned long long don2 = __ballot(alive && sp > 0);
-                if (prm.share && don2 != 0ull) {
+                if (don2 != 0ull) {
                     int target = -1;
                     if (lane == 0 && wb_load(work + RTC_WORK_HUNGRY) != 0u) {
                         const unsigned ht = wb_load(work + RTC_WORK_HINT_TAIL);
@@ -1124,8 +1222,24 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             if (RAY_CACHE || STATS) cache_id = u_cache;
             if (use_bvh && s.n_bounded > 0 && !(any_hit && T.prim >= 0)) {
                 // ---- phase 2 set-up: ordered BVH traversal, leaves tested as they are reached ----
+#ifndef RTC_SLAB_F64
+                V3 inv_d, oi;
+#endif
                 inv_d = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
                 oi = mk(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z);
+#ifndef RTC_SLAB_F64
+                // slab plane of cell index q along axis a: t = (org + q * cell - o) / d = q * (cell / d) + (org / d + oi)
+                // (f32 nodes: the planes themselves, t = plane * inv_d + oi, |plane| <= the root box's largest coordinate)
+                if (QNODES) {
+                    slab_axis(s.q_cell[0] * inv_d.x, fma(s.q_org[0], inv_d.x, oi.x), 65535., slab_ray.ax, slab_ray.bx);
+                    slab_axis(s.q_cell[1] * inv_d.y, fma(s.q_org[1], inv_d.y, oi.y), 65535., slab_ray.ay, slab_ray.by);
+                    slab_axis(s.q_cell[2] * inv_d.z, fma(s.q_org[2], inv_d.z, oi.z), 65535., slab_ray.az, slab_ray.bz);
+                } else {
+                    slab_axis(inv_d.x, oi.x, 1.000001 * fmax(fabs(s.root_min[0]), fabs(s.root_max[0])), slab_ray.ax, slab_ray.bx);
+                    slab_axis(inv_d.y, oi.y, 1.000001 * fmax(fabs(s.root_min[1]), fabs(s.root_max[1])), slab_ray.ay, slab_ray.by);
+                    slab_axis(inv_d.z, oi.z, 1.000001 * fmax(fabs(s.root_min[2]), fabs(s.root_max[2])), slab_ray.az, slab_ray.bz);
+                }
+#endif
                 pos = 0, end = 0;
                 stack[0] = RTC_NO_NODE, sb = 1;  // bottom of the stack: "pass finished"
                 double tn;
@@ -1150,9 +1264,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 const unsigned long long dead = __ballot(!alive);
                 if (!(exhausted && r_next == r_end)) {
                     if ((unsigned)__popcll(dead) >= prm.refill_min) idle |= dead;
-                } else if (idle != 0ull || __ballot(alive && sp > 0) != 0ull) {
+                } else if (idle != 0ull || (prm.share && __ballot(alive && sp > 0) != 0ull)) {
                     // tail: free lanes can take over a waiting ray, and in a wave that is mostly empty a finished lane
-                    // is served at once -- what is left of the frame is a chain of dependent rays, not throughput
+                    // is served at once -- what is left of the frame is a chain of dependent rays, not throughput.
+                    // (Without the exchange a waiting ray is no reason to leave: nobody could take it, and a wave
+                    // that left for it would come straight back -- for ever.)
                     idle |= dead;
                 }
                 if ((unsigned)__popcll(idle) >= prm.stay_min) break;
@@ -1164,6 +1280,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             stack[sb * RTC_WAVE] = (v);                             \
         else if (sb < RTC_BVH_STACK)                                \
             deep_stack[sb - RTC_LDS_STACK] = (v);                   \
+        else                                                        \
+            flag_overflow();                                        \
         sb++;                                                       \
     } while (0)
 #define RTC_POP(v)                                                                                   \
@@ -1174,6 +1292,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     } while (0)
                 const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
                 const double lo = (T.mode == MODE_CONTAINER) ? -inf : 0.;
+#ifdef RTC_SLAB_F64
                 // slab plane of cell index q along axis a: t = (org + q * cell - o) / d = q * (cell / d) + (org / d + oi)
                 // (f32 nodes: the planes themselves, t = plane * inv_d + oi)
                 const V3 q_a = QNODES ? mk(s.q_cell[0] * inv_d.x, s.q_cell[1] * inv_d.y, s.q_cell[2] * inv_d.z) : inv_d;
@@ -1181,6 +1300,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                                            fma(s.q_org[2], inv_d.z, oi.z))
                                       : oi;
                 const unsigned sel_x = near_selector_xz(q_a.x), sel_y = near_selector_y(q_a.y), sel_z = near_selector_xz(q_a.z);
+#endif
                 for (int step = 0; step < RTC_STEPS_PER_CHECK && in_pass; step++) {
                     // A step is a primitive test for lanes standing at a leaf and a short descent for the others.
                     // The primitive test is the longer half: it only runs once enough lanes wait for it (or no
@@ -1255,7 +1375,13 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     if (ref == RTC_NO_NODE) RTC_POP(ref);
                     // descend until a leaf is reached (bounded: the check above runs again after a few nodes)
                     for (int d = 0; d < RTC_NODES_PER_STEP && ref >= 0; d++) {
+#ifdef RTC_SLAB_F64
                         double tl, tr;
+#else
+                        float tl, tr;
+                        // the ray segment [lo, T.lim] in f32, rounded outward (T.lim moves when a leaf test finds a hit)
+                        const float hi32 = f32_above(T.lim), lo32 = (float)lo, lim_lo32 = f32_below(T.lim);
+#endif
                         CNT(ST_BOX, 2);
                         // containers pass: a subtree of paired primitives (spheres) matters only where its box
                         // reaches the hit point -- a sphere wholly before the hit toggles in and out again
@@ -1265,15 +1391,35 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         int cl, cr;
                         if (QNODES) {
                             const uint4 *np = (const uint4 *)(s.bvh_q + ref);
+#if RTC_LDS_TOP
+                            uint4 w0, w1;
+                            if (ref < n_top)
+                                w0 = top_nodes[2 * ref], w1 = top_nodes[2 * ref + 1];
+                            else
+                                w0 = np[0], w1 = np[1];
+#else
                             const uint4 w0 = np[0], w1 = np[1];  // both halves requested before either is used
+#endif
                             __builtin_amdgcn_sched_barrier(0);
+#ifdef RTC_SLAB_F64
                             hl = slab_q(w0.x, w0.y, w0.z, sel_x, sel_y, sel_z, q_a, q_b, (flags & 1u) ? T.lim : lo, T.lim, tl);
                             hr = slab_q(w0.w, w1.x, w1.y, sel_x, sel_y, sel_z, q_a, q_b, (flags & 2u) ? T.lim : lo, T.lim, tr);
+#else
+                            hl = slab32_q(w0.x, w0.y, w0.z, slab_ray, (flags & 1u) ? lim_lo32 : lo32, hi32, tl);
+                            hr = slab32_q(w0.w, w1.x, w1.y, slab_ray, (flags & 2u) ? lim_lo32 : lo32, hi32, tr);
+#endif
                             cl = (int)w1.z, cr = (int)w1.w;
                         } else {
                             const DBvhNode &n = s.bvh[ref];
+#ifdef RTC_SLAB_F64
                             hl = slab(n.lmin, n.lmax, q_a, q_b, (flags & 1u) ? T.lim : lo, T.lim, tl);
                             hr = slab(n.rmin, n.rmax, q_a, q_b, (flags & 2u) ? T.lim : lo, T.lim, tr);
+#else
+                            hl = slab32((f32x2){n.lmin[0], n.lmax[0]}, (f32x2){n.lmin[1], n.lmax[1]},
+                                        (f32x2){n.lmin[2], n.lmax[2]}, slab_ray, (flags & 1u) ? lim_lo32 : lo32, hi32, tl);
+                            hr = slab32((f32x2){n.rmin[0], n.rmax[0]}, (f32x2){n.rmin[1], n.rmax[1]},
+                                        (f32x2){n.rmin[2], n.rmax[2]}, slab_ray, (flags & 2u) ? lim_lo32 : lo32, hi32, tr);
+#endif
                             cl = n.left, cr = n.right;
                         }
                         // near child first, the far one waits on the stack (selects, not a branch per case)
@@ -1316,7 +1462,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         // =====================================================================================
         // state machine
         // =====================================================================================
-        bool begin_lights = false, finish = false, next_ray = false, need_shadow = false;
+        bool begin_lights = false, finish = false, next_ray = false;
         double f_refl = 0.;  // the hit material's reflectivity when `finish` is set
         SUB_BEGIN();
         if (T.mode == MODE_CLOSEST) {
@@ -1404,42 +1550,53 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         sp++;
                     } else {
                         CNT(ST_OVERFLOW, 1);
+                        flag_overflow();
                     }
                 }
             }
             begin_lights = true;
         }
         SUB_END(ST_CONTAINER);
-        if (T.mode != MODE_SHADOW) {
-        } else {
-            // World::is_shadowed (world.rs:78-91): only the NEAREST positive hit is consulted (Q5); when every
-            // material casts shadows that equals "some hit has 0 < t < distance" (any-hit early exit).
-            const bool shadowed =
-                T.prim >= 0 && (s.all_cast_shadow || s.materials[s.prims[T.prim].material].casts_shadow != 0);
-            const DLight &lt = s.lights[li];
-            // everything this block and shade_hit's tail will read of the light and the material is requested here
-            // in one go (one round trip; as separate look-ups behind each branch it was five)
-            const DMaterial m = s.materials[h_mat];
-            const int lt_area = lt.is_area;
-            const unsigned lt_usteps = lt.usteps, lt_vsteps = lt.vsteps, lt_samples = lt.samples;
-            const V3 lt_pos = ld3(lt.position), lt_int = ld3(lt.intensity);
-            __builtin_amdgcn_sched_barrier(0);
-            bool have = true;
-            double inten;
-            if (lt_area) {  // light.rs:112-125: total += 1.0 per unshadowed sample, then total / samples
-                if (!shadowed) unshadowed++;
-                su++;
-                if (su >= lt_usteps) su = 0, sv++;
-                if (sv < lt_vsteps) {
-                    have = false;
-                    need_shadow = true;
+        // ---- the lights of this hit (world.rs:45-55).  A lane comes here with the result of a shadow pass
+        // (T.mode == MODE_SHADOW) or to begin with the first light (begin_lights).  One round of the loop either
+        // consumes a result -- Material::lighting, next sample / next light / finish -- or sets up the next shadow ray.
+        // A ray whose light lies BEHIND the surface is not traced: material.rs:49-52 sets diffuse and specular to
+        // black when light_dot_normal < 0 whatever light.intensity_at() returned, so the answer of is_shadowed cannot
+        // reach the pixel; such a sample goes straight back into the loop as a result (bit-identical colours, and
+        // for the mirror / glass spheres of the stress scene about half of all shadow passes).
+        bool have_result = T.mode == MODE_SHADOW, need_setup = begin_lights, behind = false;
+        if (begin_lights) li = 0, su = sv = 0, unshadowed = 0;
+        while (have_result || need_setup) {
+            if (have_result) {
+                have_result = false;
+                // World::is_shadowed (world.rs:78-91): only the NEAREST positive hit is consulted (Q5); when every
+                // material casts shadows that equals "some hit has 0 < t < distance" (any-hit early exit).
+                const bool shadowed = !behind && T.prim >= 0 &&
+                                      (s.all_cast_shadow || s.materials[s.prims[T.prim].material].casts_shadow != 0);
+                const DLight &lt = s.lights[li];
+                // everything this block and shade_hit's tail will read of the light and the material is requested here
+                // in one go (one round trip; as separate look-ups behind each branch it was five)
+                const DMaterial m = s.materials[h_mat];
+                const int lt_area = lt.is_area;
+                const unsigned lt_usteps = lt.usteps, lt_vsteps = lt.vsteps, lt_samples = lt.samples;
+                const V3 lt_pos = ld3(lt.position), lt_int = ld3(lt.intensity);
+                __builtin_amdgcn_sched_barrier(0);
+                double inten;
+                if (behind) {
+                    inten = 0.;  // not used by lighting(): the light is behind the surface
+                } else if (lt_area) {  // light.rs:112-125: total += 1.0 per unshadowed sample, then total / samples
+                    if (!shadowed) unshadowed++;
+                    su++;
+                    if (su >= lt_usteps) su = 0, sv++;
+                    if (sv < lt_vsteps) {
+                        need_setup = true;
+                        continue;
+                    }
+                    inten = (double)unshadowed / (double)lt_samples;
+                } else {  // light.rs:50-56
+                    inten = shadowed ? 0. : 1.;
                 }
-                inten = (double)unshadowed / (double)lt_samples;
-            } else {  // light.rs:50-56
-                inten = shadowed ? 0. : 1.;
-            }
-            SUB_END(ST_PRIM0 + 0);  // (timing build: look-ups of the light block)
-            if (have) {
+                SUB_END(ST_PRIM0 + 0);  // (timing build: look-ups of the light block)
                 const V3 over = ray.o;  // the shadow ray starts at over_point (world.rs:50, 79)
                 V3 col = ld3(m.color);
                 if (PATTERNS && m.pattern >= 0) col = pattern_at_shape(s, m.pattern, s.prims[h_prim], over);
@@ -1451,17 +1608,41 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 li++;
                 su = sv = 0;
                 unshadowed = 0;
+                behind = false;
                 if (li < s.n_lights)
-                    need_shadow = true;
+                    need_setup = true;
                 else
                     finish = true, f_refl = m.reflectivity;
+            } else {
+                need_setup = false;
+                const DLight &lt = s.lights[li];
+                const int lt_area = lt.is_area;
+                V3 lp = ld3(lt.position);
+                const V3 lt_pos = lp;
+                if (lt_area)  // AreaLight::point_on_light, light.rs:106-108
+                    lp = ld3(lt.corner) + ld3(lt.uvec) * ((double)su + 0.5) + ld3(lt.vvec) * ((double)sv + 0.5);
+                const V3 h_normal = unpark3(pk, PK_NORMAL);
+                const V3 over = unpark3(pk, PK_POINT) + h_normal * RTC_EPS;
+                const V3 dv = lp - over;  // world.rs:79-83
+                ray.o = over;
+                ray.d = normalize(dv);
+                T.lim = magnitude(dv);
+                T.prim = -1;
+                T.mode = MODE_SHADOW;
+#ifndef RTC_NO_SHADOW_SKIP
+                // Material::lighting's light vector (material.rs:39): towards light.position(), which for a point
+                // light is the direction just formed
+                const V3 lightv = lt_area ? normalize(lt_pos - over) : ray.d;
+                if (dot(lightv, h_normal) < 0.) {
+                    behind = true, have_result = true;
+                    CNT(ST_SHADOW_SKIPPED, lt_area ? lt.samples : 1u);
+                    continue;
+                }
+#endif
+                CNT(ST_SHADOW, 1);
             }
         }
         SUB_END(ST_SHADOW);
-        if (begin_lights) {
-            li = 0, su = sv = 0, unshadowed = 0;
-            need_shadow = true;
-        }
         if (finish) {
             // World::shade_hit (world.rs:42-76).  The reference evaluates reflected_color/refracted_color inside
             // the per-light loop (Q3), i.e. adds them n_lights times: that factor goes into the child's weight.
@@ -1502,22 +1683,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 rays++;
             }
         }
-        if (need_shadow) {
-            const DLight &lt = s.lights[li];
-            V3 lp = ld3(lt.position);
-            if (lt.is_area)  // AreaLight::point_on_light, light.rs:106-108
-                lp = ld3(lt.corner) + ld3(lt.uvec) * ((double)su + 0.5) + ld3(lt.vvec) * ((double)sv + 0.5);
-            const V3 over = unpark3(pk, PK_POINT) + unpark3(pk, PK_NORMAL) * RTC_EPS;
-            const V3 dv = lp - over;  // world.rs:79-83
-            ray.o = over;
-            ray.d = normalize(dv);
-            T.lim = magnitude(dv);
-            T.prim = -1;
-            T.mode = MODE_SHADOW;
-            CNT(ST_SHADOW, 1);
-        }
-        if (rays > RTC_MAX_RAYS_PER_PIXEL) {
+        if (rays > (int)prm.max_rays) {
             CNT(ST_OVERFLOW, 1);
+            flag_overflow();
             park3(pk, PK_COLOR, mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.));
             alive = false;
         }
@@ -1576,7 +1744,11 @@ static void launch_variant(const DScene &scene, DRenderParams &params, double *d
         params.refill_min = refill_env ? refill_env : RTC_REFILL_MIN;
         params.dyn_base = waves;  // wave b renders tile b first
         static const int share_env = getenv("RTC_SHARE") ? atoi(getenv("RTC_SHARE")) : 1;
-        params.share = (share_env != 0 && waves <= RTC_MAX_WAVES) ? 1u : 0u;
+        if (params.refuse_oversize && params.share != 0u && waves > RTC_MAX_WAVES) {
+            params.refuse_oversize = 2u;  // reported by launch_render; nothing is launched
+            return;
+        }
+        params.share = (params.share != 0u && share_env != 0 && waves <= RTC_MAX_WAVES) ? 1u : 0u;
         params.n_waves = waves;
         static const unsigned stay_env = getenv("RTC_STAY_MIN") ? (unsigned)atoi(getenv("RTC_STAY_MIN")) : 0u;
         params.stay_min = stay_env ? stay_env : RTC_STAY_MIN;
@@ -1601,9 +1773,15 @@ static void launch_nodes(const DScene &scene, DRenderParams &params, double *d_r
 }
 
 int launch_render(const DScene &scene, const DRenderParams &params_in, double *d_rgb, uint64_t *d_stats,
-                  unsigned *d_work, unsigned n_cu, bool collect_stats, void *stream) {
+                  unsigned *d_work, unsigned n_cu, bool collect_stats, void *stream, uint32_t *launch_id_out,
+                  bool refuse_oversize) {
     DRenderParams params = params_in;
     const unsigned tiles = params.tiles_x * params.tiles_y;
+    // ids are unique per process (scenes on one GPU may share a work buffer, rtc_render_device_static) and never 0
+    const uint32_t id = next_launch_id();
+    params.launch_id = id;
+    if (launch_id_out) *launch_id_out = id;
+    if (params.max_rays == 0u || params.max_rays > 0x7fffffffu) params.max_rays = RTC_MAX_RAYS_PER_PIXEL;
     if (tiles == 0) return RTC_OK;
     hipStream_t st = (hipStream_t)stream;
     // the tile counters of the persistent grid start at zero for every launch
@@ -1611,6 +1789,7 @@ int launch_render(const DScene &scene, const DRenderParams &params_in, double *d
         set_error("hipMemsetAsync(work counter) failed");
         return RTC_ERR_HIP;
     }
+    params.refuse_oversize = refuse_oversize ? 1u : 0u;
     unsigned long long *ds = (unsigned long long *)d_stats;
     if (collect_stats)
         launch_nodes<true, true, true>(scene, params, d_rgb, ds, d_work, n_cu, st);
@@ -1620,6 +1799,11 @@ int launch_render(const DScene &scene, const DRenderParams &params_in, double *d
         launch_nodes<false, true, false>(scene, params, d_rgb, ds, d_work, n_cu, st);
     else
         launch_nodes<false, false, false>(scene, params, d_rgb, ds, d_work, n_cu, st);
+    if (params.refuse_oversize == 2u) {
+        set_error("persistent grid of more than %u resident waves: the work buffer holds that many mailboxes; set "
+                  "exchange = 1 or schedule = 1", RTC_MAX_WAVES);
+        return RTC_ERR_INVALID;
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("kernel launch failed: %s", hipGetErrorString(e));
@@ -1628,4 +1812,5 @@ int launch_render(const DScene &scene, const DRenderParams &params_in, double *d
     return RTC_OK;
 }
 
+RTC_FLAVOUR_END
 }  // namespace rtc

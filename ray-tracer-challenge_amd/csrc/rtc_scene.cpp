@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -29,20 +30,38 @@ const char *last_error() { return g_err; }
 
 Scene::~Scene() { release_device(); }
 
+uint32_t next_launch_id() {
+    static std::atomic<uint32_t> next{1u};
+    uint32_t id = next.fetch_add(1u, std::memory_order_relaxed);
+    if (id == 0u) id = next.fetch_add(1u, std::memory_order_relaxed);
+    return id;
+}
+
+DeviceGuard::DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) ok = false;
+}
+DeviceGuard::~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+}
+
 void Scene::release_device() {
-    if (device >= 0 && (!device_allocs.empty() || ev_start)) {
-        int prev = -1;
-        (void)hipGetDevice(&prev);
-        (void)hipSetDevice(device);
-        for (void *p : device_allocs) (void)hipFree(p);
-        if (ev_start) (void)hipEventDestroy((hipEvent_t)ev_start);
-        if (ev_stop) (void)hipEventDestroy((hipEvent_t)ev_stop);
-        if (prev >= 0) (void)hipSetDevice(prev);
+    for (DeviceReplica &r : reps) {
+        if (r.device < 0) continue;
+        DeviceGuard g(r.device);
+        for (void *p : r.allocs) (void)hipFree(p);
+        if (r.d_canvas) (void)hipFree(r.d_canvas);
+        if (r.ev_start) (void)hipEventDestroy((hipEvent_t)r.ev_start);
+        if (r.ev_stop) (void)hipEventDestroy((hipEvent_t)r.ev_stop);
+        if (r.stream) (void)hipStreamDestroy((hipStream_t)r.stream);
     }
-    device_allocs.clear();
-    ev_start = ev_stop = nullptr;
-    d_stats = nullptr;
-    d_work = nullptr;
+    for (void *&h : h_stage) {
+        if (h) (void)hipHostFree(h);
+        h = nullptr;
+    }
+    stage_bytes = 0;
+    reps.clear();
     device_bytes = 0;
 }
 
@@ -359,6 +378,7 @@ struct Builder {
     std::vector<int32_t> &order;
     std::vector<BuildNode> nodes;
     bool median_only;
+    uint32_t depth_limit;  // the device traversal stack bounds the depth of the tree
     uint32_t max_depth = 0;
 #ifndef RTC_BVH_MAX_LEAF
 #define RTC_BVH_MAX_LEAF 4
@@ -408,8 +428,15 @@ struct Builder {
             if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
         const double extent = cb.hi[axis] - cb.lo[axis];
 
+        // A SAH split may be arbitrarily lopsided (primitives in geometric progression, nested primitives): once the
+        // depth left would no longer cover a balanced subtree of `count` primitives, the rest of this subtree is split
+        // at the object median, whose depth is ceil(log2(count)) -- so the recursion (host stack) and the tree
+        // (device stack) both stay within depth_limit whatever the input.
+        uint32_t balanced = 0;
+        while ((1u << balanced) < (uint32_t)count) balanced++;
+        const bool force_median = median_only || depth + balanced + 1u >= depth_limit;
         int mid = -1;
-        if (!median_only && extent > 0.0) {
+        if (!force_median && extent > 0.0) {
             // binned SAH over the three axes
             double best_cost = std::numeric_limits<double>::infinity();
             int best_axis = -1, best_split = -1;
@@ -506,17 +533,10 @@ void Scene::build_bvh() {
         if (prim_bounded[i]) order.push_back((int32_t)i);
     if (order.empty()) return;
 
-    constexpr uint32_t DEPTH_LIMIT = 30;  // device traversal stack holds 32 entries
-    Builder b{prim_bounds, order, {}, false};
+    constexpr uint32_t DEPTH_LIMIT = 30;  // device traversal stack holds 32 entries (the kernel flags an overflow)
+    Builder b{prim_bounds, order, {}, false, DEPTH_LIMIT};
     b.nodes.reserve(order.size() * 2);
     b.build(0, (int)order.size(), 0);
-    if (b.max_depth > DEPTH_LIMIT) {
-        Builder m{prim_bounds, order, {}, true};
-        m.nodes.reserve(order.size() * 2);
-        m.build(0, (int)order.size(), 0);
-        b.nodes.swap(m.nodes);
-        b.max_depth = m.max_depth;
-    }
     bvh_max_depth = b.max_depth;
     // Leaf primitives in ascending flattened index (deterministic visiting order inside a leaf).
     for (const BuildNode &n : b.nodes)
@@ -627,7 +647,7 @@ void Scene::build_bvh() {
 // ---------------------------------------------------------------------------------------------
 
 template <class T>
-static int upload_vec(Scene &s, const std::vector<T> &v, const T *&dptr) {
+static int upload_vec(DeviceReplica &s, const std::vector<T> &v, const T *&dptr) {
     dptr = nullptr;
     const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
     void *p = nullptr;
@@ -636,8 +656,8 @@ static int upload_vec(Scene &s, const std::vector<T> &v, const T *&dptr) {
         set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return RTC_ERR_HIP;
     }
-    s.device_allocs.push_back(p);
-    s.device_bytes += bytes;
+    s.allocs.push_back(p);
+    s.bytes += bytes;
     if (!v.empty()) {
         e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -649,7 +669,7 @@ static int upload_vec(Scene &s, const std::vector<T> &v, const T *&dptr) {
     return RTC_OK;
 }
 
-int Scene::upload(int dev) {
+int Scene::upload(int dev, DeviceReplica &rep) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
@@ -661,33 +681,34 @@ int Scene::upload(int dev) {
         set_error("HIP device %d requested, %d present", dev, count);
         return RTC_ERR_NO_DEVICE;
     }
-    e = hipSetDevice(dev);
-    if (e != hipSuccess) {
-        set_error("hipSetDevice(%d): %s", dev, hipGetErrorString(e));
+    DeviceGuard guard(dev);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", dev);
         return RTC_ERR_HIP;
     }
-    device = dev;
+    rep.device = dev;
+    DScene &dscene = rep.dscene;
     dscene = DScene{};
     {
         std::vector<DCamera> cv(1, cam);
-        if (int rc0 = upload_vec(*this, cv, dscene.cam)) return rc0;
+        if (int rc0 = upload_vec(rep, cv, dscene.cam)) return rc0;
         dscene.hsize = cam.hsize, dscene.vsize = cam.vsize;
     }
     int rc;
-    if ((rc = upload_vec(*this, xforms, dscene.xforms))) return rc;
-    if ((rc = upload_vec(*this, chains, dscene.chains))) return rc;
-    if ((rc = upload_vec(*this, prims, dscene.prims))) return rc;
-    if ((rc = upload_vec(*this, tris, dscene.tris))) return rc;
-    if ((rc = upload_vec(*this, dmaterials, dscene.materials))) return rc;
-    if ((rc = upload_vec(*this, lights, dscene.lights))) return rc;
-    if ((rc = upload_vec(*this, dpatterns, dscene.patterns))) return rc;
+    if ((rc = upload_vec(rep, xforms, dscene.xforms))) return rc;
+    if ((rc = upload_vec(rep, chains, dscene.chains))) return rc;
+    if ((rc = upload_vec(rep, prims, dscene.prims))) return rc;
+    if ((rc = upload_vec(rep, tris, dscene.tris))) return rc;
+    if ((rc = upload_vec(rep, dmaterials, dscene.materials))) return rc;
+    if ((rc = upload_vec(rep, lights, dscene.lights))) return rc;
+    if ((rc = upload_vec(rep, dpatterns, dscene.patterns))) return rc;
     if (quantized_nodes) {
-        if ((rc = upload_vec(*this, bvh_q, dscene.bvh_q))) return rc;
+        if ((rc = upload_vec(rep, bvh_q, dscene.bvh_q))) return rc;
     } else {
-        if ((rc = upload_vec(*this, bvh, dscene.bvh))) return rc;
+        if ((rc = upload_vec(rep, bvh, dscene.bvh))) return rc;
     }
     dscene.quantized_nodes = quantized_nodes ? 1 : 0;
-    if ((rc = upload_vec(*this, bvh_flags, dscene.node_flags))) return rc;
+    if ((rc = upload_vec(rep, bvh_flags, dscene.node_flags))) return rc;
     for (int k = 0; k < 3; k++) dscene.q_org[k] = q_org[k], dscene.q_cell[k] = q_cell[k];
     {
         std::vector<int32_t> list(unbounded);
@@ -714,8 +735,8 @@ int Scene::upload(int dev) {
         std::vector<DLeaf> lv(list.size()), la(prims.size());
         for (size_t i = 0; i < list.size(); i++) lv[i] = make_leaf(list[i]);
         for (size_t i = 0; i < prims.size(); i++) la[i] = make_leaf((int32_t)i);
-        if ((rc = upload_vec(*this, lv, dscene.leaves))) return rc;
-        if ((rc = upload_vec(*this, la, dscene.leaves_all))) return rc;
+        if ((rc = upload_vec(rep, lv, dscene.leaves))) return rc;
+        if ((rc = upload_vec(rep, la, dscene.leaves_all))) return rc;
         std::vector<DLeafS> ls(compact_prims.size());
         for (size_t i = 0; i < compact_prims.size(); i++) {
             const DPrim &p = prims[compact_prims[i]];
@@ -728,7 +749,7 @@ int Scene::upload(int dev) {
                 if (std::signbit(a[off_diag[k]])) l.zsign |= 1u << k;
             for (int k = 0; k < 3; k++) l.d[k] = a[5 * k], l.t[k] = a[4 * k + 3];
         }
-        if ((rc = upload_vec(*this, ls, dscene.leaves_s))) return rc;
+        if ((rc = upload_vec(rep, ls, dscene.leaves_s))) return rc;
     }
     for (int k = 0; k < 3; k++) dscene.root_min[k] = root_min[k], dscene.root_max[k] = root_max[k];
     dscene.root_ref = root_ref;
@@ -749,8 +770,8 @@ int Scene::upload(int dev) {
     }
     std::vector<uint64_t> zeros(ST_COUNT, 0);
     const uint64_t *dst = nullptr;
-    if ((rc = upload_vec(*this, zeros, dst))) return rc;
-    d_stats = const_cast<uint64_t *>(dst);
+    if ((rc = upload_vec(rep, zeros, dst))) return rc;
+    rep.d_stats = const_cast<uint64_t *>(dst);
     {
         // tile counters + end-of-frame ray exchange of the persistent schedule (layout: rtc_types.h)
         void *pw = nullptr;
@@ -758,26 +779,27 @@ int Scene::upload(int dev) {
             set_error("hipMalloc(%zu) for the work buffer failed", (size_t)RTC_WORK_TOTAL_BYTES);
             return RTC_ERR_HIP;
         }
-        device_allocs.push_back(pw);
-        device_bytes += RTC_WORK_TOTAL_BYTES;
-        d_work = (unsigned *)pw;
+        rep.allocs.push_back(pw);
+        rep.bytes += RTC_WORK_TOTAL_BYTES;
+        rep.d_work = (unsigned *)pw;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
             set_error("hipGetDeviceProperties failed");
             return RTC_ERR_HIP;
         }
-        max_waves = (unsigned)prop.multiProcessorCount;  // CU count; the launcher multiplies by the occupancy
+        rep.n_cu = (unsigned)prop.multiProcessorCount;  // CU count; the launcher multiplies by the occupancy
     }
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
         set_error("hipEventCreate failed");
         return RTC_ERR_HIP;
     }
-    ev_start = a, ev_stop = b;
+    rep.ev_start = a, rep.ev_stop = b;
+    device_bytes += rep.bytes;
     return RTC_OK;
 }
 
-int Scene::commit(int dev) {
+int Scene::commit(const int *devices, uint32_t n_devices) {
     if (committed) {
         set_error("scene already committed");
         return RTC_ERR_STATE;
@@ -797,13 +819,39 @@ int Scene::commit(int dev) {
         return RTC_ERR_INVALID;
     }
     build_bvh();
-    if (dev >= 0) {
-        rc = upload(dev);
-        if (rc) {
-            release_device();
-            device = -1;
-            return rc;
+    device = -1;
+    if (n_devices > 0 && devices[0] >= 0) {
+        reps.resize(n_devices);
+        for (uint32_t k = 0; k < n_devices; k++) {
+            rc = devices[k] < 0 ? RTC_ERR_INVALID : upload(devices[k], reps[k]);
+            if (rc == RTC_OK && n_devices > 1) {
+                // replicas of a multi-device scene run concurrently: each renders on a stream of its own
+                DeviceGuard g(devices[k]);
+                hipStream_t st;
+                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+                    set_error("hipStreamCreate on device %d failed", devices[k]);
+                    rc = RTC_ERR_HIP;
+                } else {
+                    reps[k].stream = st;
+                }
+            }
+            if (rc) {
+                if (devices[k] < 0) set_error("device list entry %u is negative", k);
+                release_device();
+                return rc;
+            }
         }
+        device = devices[0];
+        // peer access towards the primary device (the canvas is assembled there); a failure only means that the
+        // copies are staged by the runtime
+        for (uint32_t k = 1; k < n_devices; k++)
+            if (devices[k] != device) {
+                DeviceGuard g(devices[k]);
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[k], device) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(device, 0);
+                (void)hipGetLastError();
+            }
     }
     committed = true;
     return RTC_OK;

@@ -40,6 +40,24 @@ struct Bounds {
     double lo[3], hi[3];
 };
 
+// One copy of the committed scene on one GPU (the scene is replicated per device: SURVEY.md 8(e)), with the buffers
+// the render entry points keep between calls.
+struct DeviceReplica {
+    int device = -1;
+    DScene dscene{};
+    std::vector<void *> allocs;
+    uint64_t bytes = 0;
+    uint64_t *d_stats = nullptr;  // ST_COUNT counters
+    unsigned *d_work = nullptr;   // work buffer of the render grid (layout: rtc_types.h; partly zeroed per launch)
+    unsigned n_cu = 0;            // CU count of the device (persistent grid = CUs x resident waves per CU)
+    void *ev_start = nullptr, *ev_stop = nullptr;
+    void *stream = nullptr;       // replicas of a multi-device scene render on a stream of their own
+    double *d_canvas = nullptr;   // rtc_render's device canvas: allocated at the first call, kept, grown on demand
+    size_t canvas_bytes = 0;
+    uint32_t last_launch_id = 0;  // id of the most recent launch and the work buffer it used (overflow flag)
+    unsigned *last_work = nullptr;
+};
+
 struct Scene {
     // ---- builder state ----
     std::vector<Item> items;
@@ -80,29 +98,48 @@ struct Scene {
     int32_t root_ref = 0;
     double root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 
-    // ---- device state ----
-    DScene dscene{};
-    std::vector<void *> device_allocs;
+    // ---- device state: reps[0] is the primary device (`device`), where a multi-device frame is assembled ----
+    std::vector<DeviceReplica> reps;
     uint64_t device_bytes = 0;
-    uint64_t *d_stats = nullptr;  // ST_COUNT counters
-    unsigned *d_work = nullptr;   // tile counters of the persistent render grid (8 x 128 B, zeroed per launch)
-    unsigned max_waves = 0;       // CU count of the device (persistent grid = CUs x resident waves per CU)
-    void *ev_start = nullptr, *ev_stop = nullptr;
+    void *h_stage[2] = {nullptr, nullptr};  // pinned staging buffers of rtc_render's device-to-host copy
+    size_t stage_bytes = 0;
     rtc_stats last_stats{};
     bool have_last_stats = false;
 
     ~Scene();
     int add_item(Item &&it);
-    int commit(int device);
+    int commit(const int *devices, uint32_t n_devices);  // devices[0] == -1: host-side work only
     int flatten();
     void build_bvh();
-    int upload(int device);
+    int upload(int device, DeviceReplica &r);
     void release_device();
 };
 
+// makes `device` current for the lifetime of the guard and restores the caller's device afterwards
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device);
+    ~DeviceGuard();
+};
+
+#define RTC_MAX_DEVICES 64
+
+
 // kernels (rtc_kernels.hip)
+// launch_id_out receives the id an overflowing lane of THIS launch stores into d_work[RTC_WORK_FLAG]
 int launch_render(const DScene &scene, const DRenderParams &params, double *d_rgb, uint64_t *d_stats,
-                  unsigned *d_work, unsigned n_cu, bool collect_stats, void *stream);
+                  unsigned *d_work, unsigned n_cu, bool collect_stats, void *stream, uint32_t *launch_id_out,
+                  bool refuse_oversize);
+
+namespace fastfp {  // the same kernels compiled with FMA contraction (rtc_render_opts.fp_mode = 1)
+int launch_render(const DScene &scene, const DRenderParams &params, double *d_rgb, uint64_t *d_stats,
+                  unsigned *d_work, unsigned n_cu, bool collect_stats, void *stream, uint32_t *launch_id_out,
+                  bool refuse_oversize);
+}
+
+// launch ids: unique per process (scenes on one GPU may share a work buffer), never 0
+uint32_t next_launch_id();
 
 // tiling helpers shared by the API and the launcher
 uint32_t local_rows(uint32_t vsize, uint32_t tile_rows, uint32_t tile_index, uint32_t tile_count);

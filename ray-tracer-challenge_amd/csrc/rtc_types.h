@@ -177,12 +177,16 @@ struct DScene {
 //   RTC_WORK_BUSY       waves that still have rays of their own to trace
 //   RTC_WORK_HUNGRY     waves waiting for rays of others (a hint: donors skip the search when it is 0)
 //   RTC_WORK_HINT_TAIL  number of hints published so far; RTC_WORK_HINTS: ring of 256 wave ids that went hungry
+//   RTC_WORK_FLAG       overflow flag: a lane that exceeds a per-lane bound (rays per pixel, pending refractions,
+//                       traversal stack) stores DRenderParams::launch_id here; launch ids are unique per process, so
+//                       the word needs no reset and the host compares it with the id of the launch it asks about
 //   RTC_WORK_STATES     per wave: mailbox state (RTC_MB_*);  RTC_WORK_COUNTS: per wave: rays in its mailbox
 //   byte RTC_WORK_MBOX_BYTES on: per wave one mailbox of 64 rays x RTC_MBOX_ITEM_U64 x 8 bytes
 #define RTC_MAX_WAVES 4096u
 #define RTC_WORK_BUSY 256u
 #define RTC_WORK_HUNGRY 288u
 #define RTC_WORK_HINT_TAIL 320u
+#define RTC_WORK_FLAG 352u  // id of the most recent launch in which a lane exceeded one of the kernel's per-lane bounds
 #define RTC_WORK_HINTS 512u
 #define RTC_WORK_STATES 1024u
 #define RTC_WORK_COUNTS (RTC_WORK_STATES + RTC_MAX_WAVES)
@@ -206,6 +210,10 @@ struct DRenderParams {
     uint32_t n_waves;           // size of the persistent grid
     uint32_t tile_order;        // 0: tiles are handed out top row first, 1: bottom row first
     uint32_t leaf_den;          // primitive tests run when at least 1/leaf_den of the traversing lanes wait at a leaf
+    uint32_t launch_id;         // process-wide unique, never 0: what an overflowing lane stores into work[RTC_WORK_FLAG]
+    uint32_t max_rays;          // rays one lane may trace for one pixel (or adopted subtree) before it gives up
+    uint32_t fast;              // rtc_render_opts.fp_mode: 1 selects the kernels compiled with FMA contraction
+    uint32_t refuse_oversize;   // host only: 1 = a grid beyond RTC_MAX_WAVES with the exchange on is an error (2 = it was)
 };
 
 // device-side counters, one uint64 each (index constants)
@@ -223,6 +231,7 @@ enum StatIdx {
     ST_SCHLICK,
     ST_REFRACT,
     ST_OVERFLOW,
+    ST_SHADOW_SKIPPED,  // is_shadowed queries answered without a trace: the light is behind the surface
     // diagnostics of the counting kernel: shader cycles (s_memtime) a wave spent per stage, summed over waves, and
     // how many lanes took part -- where the time of a divergent workload goes
     ST_CYC_REFILL,

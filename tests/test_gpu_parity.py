@@ -175,3 +175,23 @@ def test_rt_run_cli_writes_the_reference_ppm(tmp_path):
     world, cam = sf.load("reflective_world", 100, 50)
     ref = sf.to_oracle(world, cam).render()
     assert got == orc.canvas_to_ppm(ref)
+
+
+def test_stress_scene_headline_frame_depth5_matches_oracle():
+    # the headline configuration itself -- 100k spheres + teapot, 3840x2160, depth 5, default (persistent +
+    # exchange) schedule -- against the oracle on a regular grid of its pixels (the brute-force oracle needs ~3 ms per
+    # ray, so the grid is sized for some tens of seconds of CPU time)
+    world, cam = rtc.stress_scene.build(100_000, 3840, 2160)
+    scene = cam.compile(world, device=0)
+    try:
+        gpu = scene.render()
+    finally:
+        scene.close()
+    rows, cols = slice(61, 2159, 270), slice(0, 3839, 480)
+    ref = sf.to_oracle(world, cam).render(subset=(61, 2160, 270, 480))
+    rep = sf.compare(gpu[rows, cols], ref[rows, cols])
+    n = gpu[rows, cols].shape[0] * gpu[rows, cols].shape[1]
+    print(f"[parity] stress 100k 4K depth 5, {n} oracle pixels: {rep}")
+    assert n == 64 and float(np.abs(ref[rows, cols]).sum()) > 0
+    assert rep["nan"] == 0 and rep["max_8bit"] <= 1 and rep["max_abs"] < F64_TOL, rep
+    assert not np.isnan(gpu).any()
