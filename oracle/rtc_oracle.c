@@ -451,7 +451,14 @@ int orc_add_pattern(orc_world *w, int kind, const double a[3], const double b[3]
 }
 
 static int add_shape_common(orc_world *w, int kind, int parent, const mat4 *t, int material) {
-    if (parent >= w->nshapes || (parent >= 0 && w->shapes[parent].kind != ORC_GROUP)) return -ORC_ERR_INVALID;
+    if (parent >= w->nshapes) return -ORC_ERR_INVALID;
+    if (parent >= 0 && w->shapes[parent].kind != ORC_GROUP && w->shapes[parent].kind != ORC_CSG) return -ORC_ERR_INVALID;
+    if (parent >= 0 && w->shapes[parent].kind == ORC_CSG) {
+        /* Csg::new takes exactly a left and a right shape; a triangle under a Csg panics in Triangle::material()
+         * (shape.rs:1521-1523: parent.as_group().unwrap()) */
+        if (w->shapes[parent].nchildren >= 2 || kind == ORC_TRIANGLE || kind == ORC_SMOOTH_TRIANGLE)
+            return -ORC_ERR_INVALID;
+    }
     GROW(w->shapes, w->nshapes, w->cap_shapes, shape_t);
     shape_t *s = &w->shapes[w->nshapes];
     memset(s, 0, sizeof *s);
@@ -486,6 +493,16 @@ int orc_add_shape(orc_world *w, int kind, int parent, const double transform[16]
         s->maximum = maximum;
         s->closed = closed;
     }
+    return idx;
+}
+
+/* shape.rs:2166-2184; Csg::transformation() is the identity (shape.rs:2250-2252) */
+int orc_add_csg(orc_world *w, int parent, int operation) {
+    if (operation < ORC_CSG_UNION || operation > ORC_CSG_DIFFERENCE) return -ORC_ERR_INVALID;
+    mat4 t = m_identity();
+    int idx = add_shape_common(w, ORC_CSG, parent, &t, -1);
+    if (idx < 0) return idx;
+    w->shapes[idx].closed = operation;
     return idx;
 }
 
@@ -753,12 +770,54 @@ static void triangle_local_intersect(const shape_t *s, int self, const ray_t *ra
 
 static void shape_local_intersect(const orc_world *w, int self, const ray_t *local, xs_t *out);
 
+/* Shape::includes: a leaf includes itself (shape.rs:136-138: same id and type), a Group whatever one of its children
+ * includes (shape.rs:2023-2030), a Csg whatever its left or right includes (shape.rs:2278-2280) */
+static int shape_includes(const orc_world *w, int self, int object) {
+    const shape_t *s = &w->shapes[self];
+    if (s->kind == ORC_GROUP || s->kind == ORC_CSG) {
+        for (int i = 0; i < s->nchildren; i++)
+            if (shape_includes(w, s->children[i], object)) return 1;
+        return 0;
+    }
+    return self == object;
+}
+
+/* shape.rs:2186-2197 */
+static int csg_intersection_allowed(int operation, int left_hit, int in_left, int in_right) {
+    switch (operation) {
+    case ORC_CSG_UNION: return (left_hit && !in_right) || (!left_hit && !in_left);
+    case ORC_CSG_INTERSECTION: return (left_hit && in_right) || (!left_hit && in_left);
+    default: return (left_hit && !in_right) || (!left_hit && in_left); /* Difference */
+    }
+}
+
+/* shape.rs:2203-2225 on out->data[from..n): the records that pass are moved to the front of that range */
+static void csg_filter(const orc_world *w, int self, xs_t *out, int from) {
+    const shape_t *s = &w->shapes[self];
+    int in_left = 0, in_right = 0, keep = from;
+    for (int i = from; i < out->n; i++) {
+        const int left_hit = s->nchildren > 0 && shape_includes(w, s->children[0], out->data[i].shape);
+        if (csg_intersection_allowed(s->closed, left_hit, in_left, in_right)) out->data[keep++] = out->data[i];
+        if (left_hit)
+            in_left = !in_left;
+        else
+            in_right = !in_right;
+    }
+    out->n = keep;
+}
+
 /* <Shape as Intersect>::intersect: shape.rs:255-258, 539-542, 781-784, 1014-1017, 1346-1349,
  * 1506-1508 (triangles: no ray.transform), 2033-2038 (groups) */
 static void shape_intersect(const orc_world *w, int self, const ray_t *ray, xs_t *out) {
     const shape_t *s = &w->shapes[self];
     if (s->kind == ORC_TRIANGLE || s->kind == ORC_SMOOTH_TRIANGLE) {
         triangle_local_intersect(s, self, ray, out);
+        return;
+    }
+    if (s->kind == ORC_CSG) {
+        /* shape.rs:2238-2243: ray.transform(self.transformation()) -- the identity itself, not its inverse */
+        ray_t local = ray_transform(ray, &s->transform);
+        shape_local_intersect(w, self, &local, out);
         return;
     }
     ray_t local = ray_transform(ray, &s->inverse);
@@ -780,6 +839,15 @@ static void shape_local_intersect(const orc_world *w, int self, const ray_t *loc
         int from = out->n;
         for (int i = 0; i < s->nchildren; i++) shape_intersect(w, s->children[i], local, out);
         xs_sort_from(out, from);
+        break;
+    }
+    case ORC_CSG: {
+        /* shape.rs:2227-2235: left's records, then right's, sorted (see the header comment on sort_unstable_by),
+         * filtered */
+        int from = out->n;
+        for (int i = 0; i < s->nchildren && i < 2; i++) shape_intersect(w, s->children[i], local, out);
+        xs_sort_from(out, from);
+        csg_filter(w, self, out, from);
         break;
     }
     default: break; /* TestShape::intersect is unimplemented!() (shape.rs:2459-2461) */
@@ -1344,6 +1412,25 @@ int orc_normal_to_world(orc_world *w, int shape, const double n[3], double out[3
     out3(shape_normal_to_world(w, shape, in3(n)), out);
     return ORC_OK;
 }
+int orc_csg_intersection_allowed(int operation, int left_hit, int in_left, int in_right) {
+    return csg_intersection_allowed(operation, left_hit, in_left, in_right);
+}
+int orc_csg_filter(orc_world *w, int csg, int n, const double *ts, const int *shapes, int *kept) {
+    if (csg < 0 || csg >= w->nshapes || w->shapes[csg].kind != ORC_CSG) return -ORC_ERR_INVALID;
+    xs_t xs;
+    xs_init(&xs);
+    for (int i = 0; i < n; i++) xs_push(&xs, ts[i], shapes[i], (double)i, 0.); /* u carries the input position */
+    csg_filter(w, csg, &xs, 0);
+    const int m = xs.n;
+    for (int i = 0; i < m; i++) kept[i] = (int)xs.data[i].u;
+    xs_free(&xs);
+    return m;
+}
+int orc_shape_includes(orc_world *w, int shape, int object) {
+    if (shape < 0 || shape >= w->nshapes || object < 0 || object >= w->nshapes) return -ORC_ERR_INVALID;
+    return shape_includes(w, shape, object);
+}
+
 int orc_color_at(orc_world *w, const double origin[3], const double direction[3], int remaining, double rgb[3]) {
     if (!world_check_invertible(w)) return ORC_ERR_NON_INVERTIBLE;
     ray_t r = {in3(origin), in3(direction)};

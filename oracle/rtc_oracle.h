@@ -35,7 +35,8 @@ enum {
     ORC_TRIANGLE = 5,
     ORC_SMOOTH_TRIANGLE = 6,
     ORC_GROUP = 7,
-    ORC_TEST_SHAPE = 8
+    ORC_TEST_SHAPE = 8,
+    ORC_CSG = 9 /* shape.rs:2146-2291; `closed` carries the CsgOp, the first two children are left and right */
 };
 
 /* pattern kinds -- ray_tracer/src/pattern.rs:5-15 (Perturbed excluded: un-vendored perlin_noise) */
@@ -51,6 +52,8 @@ enum {
 };
 
 enum { ORC_OK = 0, ORC_ERR_NON_INVERTIBLE = 1, ORC_ERR_INVALID = 2 };
+/* CsgOp, shape.rs:2149-2154 */
+enum { ORC_CSG_UNION = 0, ORC_CSG_INTERSECTION = 1, ORC_CSG_DIFFERENCE = 2 };
 
 typedef struct orc_world orc_world;
 
@@ -109,6 +112,15 @@ int orc_add_area_light(orc_world *w, const double corner[3], const double full_u
                        const double full_vvec[3], uint32_t vsteps, const double intensity[3]);
 int orc_set_camera(orc_world *w, uint32_t hsize, uint32_t vsize, double field_of_view, const double view[16]);
 int orc_shape_set_material(orc_world *w, int shape, int material);
+/* Csg::new(operation, left, right) (shape.rs:2166-2184): the node is added first, left and right are then added with
+ * the node as their parent (first child = left, second = right; a third child is refused).  Returns the shape index. */
+int orc_add_csg(orc_world *w, int parent, int operation);
+/* Csg::intersection_allowed (shape.rs:2186-2197) and Csg::filter_intersections (shape.rs:2203-2225) on an explicit
+ * list: xs given as n (t, shape) records; writes the indices of the records that pass, returns their number */
+int orc_csg_intersection_allowed(int operation, int left_hit, int in_left, int in_right);
+int orc_csg_filter(orc_world *w, int csg, int n, const double *ts, const int *shapes, int *kept);
+/* Shape::includes (shape.rs:136-138, 2023-2030, 2278-2280) */
+int orc_shape_includes(orc_world *w, int shape, int object);
 
 /* ---- the hot path ---- */
 /* Camera::render (camera.rs:64-93): rgb_out is vsize*hsize*3 doubles, row-major, last row and

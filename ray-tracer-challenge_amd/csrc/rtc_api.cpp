@@ -636,7 +636,7 @@ int rtc_scene_get_info(rtc_scene *scene, rtc_scene_info *out) {
     out->hsize = s.hsize, out->vsize = s.vsize;
     out->n_prims = (uint32_t)s.prims.size();
     out->n_unbounded = (uint32_t)s.unbounded.size();
-    out->n_bvh_nodes = (uint32_t)s.bvh.size();
+    out->n_bvh_nodes = (uint32_t)((s.quantized_nodes && RTC_BVH4) ? s.bvh4.size() : s.bvh.size());
     out->n_xforms = (uint32_t)s.xforms.size();
     out->n_materials = (uint32_t)s.materials.size();
     out->n_lights = (uint32_t)s.lights.size();

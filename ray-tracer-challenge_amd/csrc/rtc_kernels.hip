@@ -43,7 +43,7 @@ RTC_FLAVOUR_BEGIN
 
 #define RTC_EPS 1e-5  // lib.rs:24
 #define RTC_WAVE 64
-#define RTC_BVH_STACK 32
+#define RTC_BVH_STACK 96  // a four-wide node pushes up to three references: 3 x depth in the worst case
 #define RTC_MAX_DEPTH_STACK 8
 #ifndef RTC_MAX_RAYS_PER_PIXEL
 #define RTC_MAX_RAYS_PER_PIXEL 65536
@@ -56,6 +56,9 @@ RTC_FLAVOUR_BEGIN
 #define RTC_NODES_PER_STEP 2          // BVH nodes one step may descend through
 #endif
 #define RTC_SHARDS 8u  // tile counters of the persistent grid
+#ifndef RTC_NODES4_PER_STEP
+#define RTC_NODES4_PER_STEP 1         // the same for the four-wide nodes of large hierarchies
+#endif
 #ifndef RTC_STAY_MIN
 #define RTC_STAY_MIN 16  // waiting lanes (finished pass / free) at which a wave leaves the traversal loop to serve them
 #endif
@@ -540,7 +543,7 @@ DEV bool slab(const F *bmin, const F *bmax, const V3 &inv_d, const V3 &oi, doubl
     tnear = tn;
     return tn <= tf;
 }
-// ---- the traversal's own slab test, in f32 (RTC_SLAB_F64 keeps the f64 form of round 1 for A/B) ----
+// ---- the traversal's own slab test, in f32 ----
 // Box planes are exact in f32 (16-bit cell indices, or f32 planes); what is rounded is the ray's slope a = 1/d (times
 // the cell size) and intercept b = (origin of the frame - ray origin)/d, each once from their f64 values, and the
 // fma itself: |error of t| <= 2^-23 (qmax |a| + |b|) for every plane of the scene.  That bound e is folded into the
@@ -587,28 +590,6 @@ DEV bool slab32_q(unsigned d0, unsigned d1, unsigned d2, const SlabRay &R, float
 DEV float f32_above(double x) { return (float)(x * (1. + 0x1p-22)); }
 DEV float f32_below(double x) { return (float)(x * (1. - 0x1p-22)); }
 
-#ifdef RTC_SLAB_F64
-// Quantised boxes: both children of a DBvhNodeQ against one ray.  The near / far plane of an axis is known from
-// the sign of the ray direction, so each plane index is picked out of the node's dwords by ONE v_perm_b32 with a
-// per-lane selector (extraction and near/far choice in a single instruction), and no min/max per axis is needed:
-// t(q) = q * q_a + q_b is monotonic in q, so the result equals min/max of the two planes' distances bit for bit.
-// Node dwords: d0 = min.x | min.y << 16, d1 = min.z | max.x << 16, d2 = max.y | max.z << 16.
-#define RTC_SEL_FLIP 0x0606u  // near selector ^ far selector, same for the three axes
-DEV unsigned near_selector_xz(double qa) { return qa >= 0. ? 0x0c0c0100u : 0x0c0c0706u; }  // perm(d1|d2, d0|d1)
-DEV unsigned near_selector_y(double qa) { return qa >= 0. ? 0x0c0c0302u : 0x0c0c0504u; }   // perm(d2, d0)
-DEV bool slab_q(unsigned d0, unsigned d1, unsigned d2, unsigned sx, unsigned sy, unsigned sz, const V3 &q_a,
-                const V3 &q_b, double lo, double hi, double &tnear) {
-    const double nx = (double)__builtin_amdgcn_perm(d1, d0, sx), fx = (double)__builtin_amdgcn_perm(d1, d0, sx ^ RTC_SEL_FLIP);
-    const double ny = (double)__builtin_amdgcn_perm(d2, d0, sy), fy = (double)__builtin_amdgcn_perm(d2, d0, sy ^ RTC_SEL_FLIP);
-    const double nz = (double)__builtin_amdgcn_perm(d2, d1, sz), fz = (double)__builtin_amdgcn_perm(d2, d1, sz ^ RTC_SEL_FLIP);
-    double tn = fma(nx, q_a.x, q_b.x), tf = fma(fx, q_a.x, q_b.x);
-    tn = fmax(tn, fma(ny, q_a.y, q_b.y)), tf = fmin(tf, fma(fy, q_a.y, q_b.y));
-    tn = fmax(tn, fma(nz, q_a.z, q_b.z)), tf = fmin(tf, fma(fz, q_a.z, q_b.z));
-    tn = fmax(tn, lo), tf = fmin(tf, hi);
-    tnear = tn;
-    return tn <= tf;
-}
-#endif
 DEV double safe_rcp(double d) {
     const double r = __builtin_amdgcn_rcp(d);
     const double a = fmin(fabs(r), 1e30);  // d == 0 (or denormal): a huge finite slope keeps fma() NaN-free
@@ -799,7 +780,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     // top levels -- copied into LDS by every wave.  LDS is what bounds the occupancy (12.8 KB per wave x 12 waves of the
     // CU's 160 KB), so the copy has to be paid for with traversal-stack entries (build with a smaller RTC_LDS_STACK).
     __shared__ uint4 top_nodes[RTC_LDS_TOP * 2];
-    const int n_top = QNODES ? (s.n_bvh_nodes < RTC_LDS_TOP ? s.n_bvh_nodes : RTC_LDS_TOP) : 0;
+    const int n_top = (QNODES && !RTC_BVH4) ? (s.n_bvh_nodes < RTC_LDS_TOP ? s.n_bvh_nodes : RTC_LDS_TOP) : 0;
     if (QNODES)
         for (int i = (int)threadIdx.x; i < n_top * 2; i += RTC_WAVE) top_nodes[i] = ((const uint4 *)s.bvh_q)[i];
 #endif
@@ -853,13 +834,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     // ---- BVH traversal state of the pass in flight (resumable) ----
     bool in_pass = false;
     int pos = 0, end = 0, sb = 0, cur = RTC_NO_NODE;
-#ifdef RTC_SLAB_F64
-    V3 inv_d = mk(0., 0., 0.), oi = mk(0., 0., 0.);
-#else
     SlabRay slab_ray;  // this pass's ray in the slab test's f32 form (persists with the traversal)
     slab_ray.ax = slab_ray.ay = slab_ray.az = 0.f;
     slab_ray.bx = slab_ray.by = slab_ray.bz = (f32x2){0.f, 0.f};
-#endif
     // The ray in group space is cached per lane across the leaves of a pass when primitives sit in groups.  The
     // persistent schedule is chosen for glass-heavy scenes, where the 13 registers this costs between passes are
     // worth more than the transform it saves: there the ray is transformed per grouped leaf.
@@ -1222,12 +1199,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             if (RAY_CACHE || STATS) cache_id = u_cache;
             if (use_bvh && s.n_bounded > 0 && !(any_hit && T.prim >= 0)) {
                 // ---- phase 2 set-up: ordered BVH traversal, leaves tested as they are reached ----
-#ifndef RTC_SLAB_F64
                 V3 inv_d, oi;
-#endif
                 inv_d = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
                 oi = mk(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z);
-#ifndef RTC_SLAB_F64
                 // slab plane of cell index q along axis a: t = (org + q * cell - o) / d = q * (cell / d) + (org / d + oi)
                 // (f32 nodes: the planes themselves, t = plane * inv_d + oi, |plane| <= the root box's largest coordinate)
                 if (QNODES) {
@@ -1239,7 +1213,6 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     slab_axis(inv_d.y, oi.y, 1.000001 * fmax(fabs(s.root_min[1]), fabs(s.root_max[1])), slab_ray.ay, slab_ray.by);
                     slab_axis(inv_d.z, oi.z, 1.000001 * fmax(fabs(s.root_min[2]), fabs(s.root_max[2])), slab_ray.az, slab_ray.bz);
                 }
-#endif
                 pos = 0, end = 0;
                 stack[0] = RTC_NO_NODE, sb = 1;  // bottom of the stack: "pass finished"
                 double tn;
@@ -1292,15 +1265,6 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     } while (0)
                 const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
                 const double lo = (T.mode == MODE_CONTAINER) ? -inf : 0.;
-#ifdef RTC_SLAB_F64
-                // slab plane of cell index q along axis a: t = (org + q * cell - o) / d = q * (cell / d) + (org / d + oi)
-                // (f32 nodes: the planes themselves, t = plane * inv_d + oi)
-                const V3 q_a = QNODES ? mk(s.q_cell[0] * inv_d.x, s.q_cell[1] * inv_d.y, s.q_cell[2] * inv_d.z) : inv_d;
-                const V3 q_b = QNODES ? mk(fma(s.q_org[0], inv_d.x, oi.x), fma(s.q_org[1], inv_d.y, oi.y),
-                                           fma(s.q_org[2], inv_d.z, oi.z))
-                                      : oi;
-                const unsigned sel_x = near_selector_xz(q_a.x), sel_y = near_selector_y(q_a.y), sel_z = near_selector_xz(q_a.z);
-#endif
                 for (int step = 0; step < RTC_STEPS_PER_CHECK && in_pass; step++) {
                     // A step is a primitive test for lanes standing at a leaf and a short descent for the others.
                     // The primitive test is the longer half: it only runs once enough lanes wait for it (or no
@@ -1374,20 +1338,47 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     int ref = cur;
                     if (ref == RTC_NO_NODE) RTC_POP(ref);
                     // descend until a leaf is reached (bounded: the check above runs again after a few nodes)
-                    for (int d = 0; d < RTC_NODES_PER_STEP && ref >= 0; d++) {
-#ifdef RTC_SLAB_F64
-                        double tl, tr;
-#else
-                        float tl, tr;
-                        // the ray segment [lo, T.lim] in f32, rounded outward (T.lim moves when a leaf test finds a hit)
-                        const float hi32 = f32_above(T.lim), lo32 = (float)lo, lim_lo32 = f32_below(T.lim);
-#endif
-                        CNT(ST_BOX, 2);
+                    for (int d = 0; d < ((QNODES && RTC_BVH4) ? RTC_NODES4_PER_STEP : RTC_NODES_PER_STEP) && ref >= 0; d++) {
                         // containers pass: a subtree of paired primitives (spheres) matters only where its box
                         // reaches the hit point -- a sphere wholly before the hit toggles in and out again
                         const bool cont = T.mode == MODE_CONTAINER;
                         const unsigned flags = cont ? s.node_flags[ref] : 0u;
                         bool hl, hr;
+                        // the ray segment [lo, T.lim] in f32, rounded outward (T.lim moves when a leaf test finds a hit)
+                        const float hi32 = f32_above(T.lim), lo32 = (float)lo, lim_lo32 = f32_below(T.lim);
+                        if (QNODES && RTC_BVH4) {
+                            // ---- four children per node (DBvhNode4): one 64-byte fetch per two levels of the binary tree ----
+                            CNT(ST_BOX, 4);
+                            const uint4 *np = (const uint4 *)(s.bvh4 + ref);
+                            const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];  // requested before any is used
+                            __builtin_amdgcn_sched_barrier(0);
+                            float t0, t1, t2, t3;
+                            const bool h0 = slab32_q(w0.x, w0.y, w0.z, slab_ray, (flags & 1u) ? lim_lo32 : lo32, hi32, t0);
+                            const bool h1 = slab32_q(w0.w, w1.x, w1.y, slab_ray, (flags & 2u) ? lim_lo32 : lo32, hi32, t1);
+                            // (slots 2 and 3 may be unused: their inverted boxes miss, and the reference is checked so
+                            // that no rounding, however far-fetched, can turn RTC_NO_CHILD into the node to visit)
+                            const bool h2 = slab32_q(w1.z, w1.w, w2.x, slab_ray, (flags & 4u) ? lim_lo32 : lo32, hi32, t2) &&
+                                            (int)w3.z != RTC_NO_CHILD;
+                            const bool h3 = slab32_q(w2.y, w2.z, w2.w, slab_ray, (flags & 8u) ? lim_lo32 : lo32, hi32, t3) &&
+                                            (int)w3.w != RTC_NO_CHILD;
+                            if (!(h0 || h1 || h2 || h3)) {
+                                RTC_POP(ref);
+                                continue;
+                            }
+                            // the nearest child that was hit goes first, the other hits wait on the stack
+                            const float inf32 = __builtin_inff();
+                            const float u0 = h0 ? t0 : inf32, u1 = h1 ? t1 : inf32, u2 = h2 ? t2 : inf32, u3 = h3 ? t3 : inf32;
+                            const float tmin = __builtin_fminf(__builtin_fminf(u0, u1), __builtin_fminf(u2, u3));
+                            const int sel = (h0 && u0 == tmin) ? 0 : (h1 && u1 == tmin) ? 1 : (h2 && u2 == tmin) ? 2 : 3;
+                            if (h3 && sel != 3) RTC_PUSH((int)w3.w);
+                            if (h2 && sel != 2) RTC_PUSH((int)w3.z);
+                            if (h1 && sel != 1) RTC_PUSH((int)w3.y);
+                            if (h0 && sel != 0) RTC_PUSH((int)w3.x);
+                            ref = sel == 0 ? (int)w3.x : sel == 1 ? (int)w3.y : sel == 2 ? (int)w3.z : (int)w3.w;
+                            continue;
+                        }
+                        float tl, tr;
+                        CNT(ST_BOX, 2);
                         int cl, cr;
                         if (QNODES) {
                             const uint4 *np = (const uint4 *)(s.bvh_q + ref);
@@ -1401,25 +1392,15 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                             const uint4 w0 = np[0], w1 = np[1];  // both halves requested before either is used
 #endif
                             __builtin_amdgcn_sched_barrier(0);
-#ifdef RTC_SLAB_F64
-                            hl = slab_q(w0.x, w0.y, w0.z, sel_x, sel_y, sel_z, q_a, q_b, (flags & 1u) ? T.lim : lo, T.lim, tl);
-                            hr = slab_q(w0.w, w1.x, w1.y, sel_x, sel_y, sel_z, q_a, q_b, (flags & 2u) ? T.lim : lo, T.lim, tr);
-#else
                             hl = slab32_q(w0.x, w0.y, w0.z, slab_ray, (flags & 1u) ? lim_lo32 : lo32, hi32, tl);
                             hr = slab32_q(w0.w, w1.x, w1.y, slab_ray, (flags & 2u) ? lim_lo32 : lo32, hi32, tr);
-#endif
                             cl = (int)w1.z, cr = (int)w1.w;
                         } else {
                             const DBvhNode &n = s.bvh[ref];
-#ifdef RTC_SLAB_F64
-                            hl = slab(n.lmin, n.lmax, q_a, q_b, (flags & 1u) ? T.lim : lo, T.lim, tl);
-                            hr = slab(n.rmin, n.rmax, q_a, q_b, (flags & 2u) ? T.lim : lo, T.lim, tr);
-#else
                             hl = slab32((f32x2){n.lmin[0], n.lmax[0]}, (f32x2){n.lmin[1], n.lmax[1]},
                                         (f32x2){n.lmin[2], n.lmax[2]}, slab_ray, (flags & 1u) ? lim_lo32 : lo32, hi32, tl);
                             hr = slab32((f32x2){n.rmin[0], n.rmax[0]}, (f32x2){n.rmin[1], n.rmax[1]},
                                         (f32x2){n.rmin[2], n.rmax[2]}, slab_ray, (flags & 2u) ? lim_lo32 : lo32, hi32, tr);
-#endif
                             cl = n.left, cr = n.right;
                         }
                         // near child first, the far one waits on the stack (selects, not a branch per case)

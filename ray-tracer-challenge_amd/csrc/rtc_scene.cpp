@@ -523,7 +523,7 @@ static float f32_up(double v) {
 }
 
 void Scene::build_bvh() {
-    bvh.clear(), bvh_q.clear(), bvh_prims.clear(), bvh_flags.clear(), compact_prims.clear();
+    bvh.clear(), bvh4.clear(), bvh_q.clear(), bvh_prims.clear(), bvh_flags.clear(), compact_prims.clear();
     quantized_nodes = false;
     bvh_max_depth = 0, bvh_max_leaf = 0;
     root_ref = 0;
@@ -618,25 +618,92 @@ void Scene::build_bvh() {
             while (q < 65535.0 && q_org[k] + q * q_cell[k] < v) q += 1.0;
             return (uint16_t)q;
         };
-        // hierarchies beyond 1 MB of f32 nodes are stored quantised (rtc_types.h)
+        // hierarchies beyond 1 MB of f32 nodes are stored quantised and four wide (rtc_types.h)
         quantized_nodes = (size_t)next * sizeof(DBvhNode) > (1u << 20);
-        bvh_q.resize(quantized_nodes ? next : 0);
-        for (int t : queue) {
-            const BuildNode &n = b.nodes[t];
-            const BuildNode &l = b.nodes[n.left], &r = b.nodes[n.right];
-            DBvhNode d{};
-            DBvhNodeQ q{};
-            for (int k = 0; k < 3; k++) {
-                d.lmin[k] = f32_down(l.b.lo[k]), d.lmax[k] = f32_up(l.b.hi[k]);
-                d.rmin[k] = f32_down(r.b.lo[k]), d.rmax[k] = f32_up(r.b.hi[k]);
-                q.lmin[k] = q_down(l.b.lo[k], k), q.lmax[k] = q_up(l.b.hi[k], k);
-                q.rmin[k] = q_down(r.b.lo[k], k), q.rmax[k] = q_up(r.b.hi[k], k);
+        // a leaf's reference is formed once (forming it appends to the compact list)
+        std::vector<int32_t> ref_of(b.nodes.size(), 0);
+        std::vector<uint8_t> ref_done(b.nodes.size(), 0);
+        auto child_ref = [&](int c, const std::vector<int> &index) -> int32_t {
+            if (b.nodes[c].left >= 0) return index[c];
+            if (!ref_done[c]) ref_of[c] = leaf_ref(b.nodes[c]), ref_done[c] = 1;
+            return ref_of[c];
+        };
+        if (!quantized_nodes || !RTC_BVH4) {
+            bvh_q.resize(quantized_nodes ? next : 0);
+            for (int t : queue) {
+                const BuildNode &n = b.nodes[t];
+                const BuildNode &l = b.nodes[n.left], &r = b.nodes[n.right];
+                DBvhNode d{};
+                DBvhNodeQ q{};
+                for (int k = 0; k < 3; k++) {
+                    d.lmin[k] = f32_down(l.b.lo[k]), d.lmax[k] = f32_up(l.b.hi[k]);
+                    d.rmin[k] = f32_down(r.b.lo[k]), d.rmax[k] = f32_up(r.b.hi[k]);
+                    q.lmin[k] = q_down(l.b.lo[k], k), q.lmax[k] = q_up(l.b.hi[k], k);
+                    q.rmin[k] = q_down(r.b.lo[k], k), q.rmax[k] = q_up(r.b.hi[k], k);
+                }
+                q.left = d.left = child_ref(n.left, new_index);
+                q.right = d.right = child_ref(n.right, new_index);
+                bvh_flags[new_index[t]] = (uint8_t)((paired[n.left] ? 1 : 0) | (paired[n.right] ? 2 : 0));
+                bvh[new_index[t]] = d;
+                if (quantized_nodes) bvh_q[new_index[t]] = q;
             }
-            q.left = d.left = (l.left >= 0) ? new_index[n.left] : leaf_ref(l);
-            q.right = d.right = (r.left >= 0) ? new_index[n.right] : leaf_ref(r);
-            bvh_flags[new_index[t]] = (uint8_t)((paired[n.left] ? 1 : 0) | (paired[n.right] ? 2 : 0));
-            bvh[new_index[t]] = d;
-            if (quantized_nodes) bvh_q[new_index[t]] = q;
+        } else {
+            // ---- four-wide: a node adopts its grandchildren -- the internal child with the largest box first -- until
+            // it has four children or only leaves are left; breadth-first order again ----
+            auto kids_of = [&](int t, int kids[4]) {
+                int n = 0;
+                kids[n++] = b.nodes[t].left, kids[n++] = b.nodes[t].right;
+                while (n < 4) {
+                    int best = -1;
+                    double best_area = -1.0;
+                    for (int i = 0; i < n; i++)
+                        if (b.nodes[kids[i]].left >= 0) {
+                            const double a = Builder::area(b.nodes[kids[i]].b);
+                            if (a > best_area) best_area = a, best = i;
+                        }
+                    if (best < 0) break;
+                    const int c = kids[best];
+                    kids[best] = b.nodes[c].left;
+                    kids[n++] = b.nodes[c].right;
+                }
+                return n;
+            };
+            std::vector<int> queue4{0};
+            std::vector<int> index4(b.nodes.size(), -1);
+            index4[0] = 0;
+            int next4 = 1;
+            for (size_t head = 0; head < queue4.size(); head++) {
+                int kids[4];
+                const int n = kids_of(queue4[head], kids);
+                for (int i = 0; i < n; i++)
+                    if (b.nodes[kids[i]].left >= 0) {
+                        index4[kids[i]] = next4++;
+                        queue4.push_back(kids[i]);
+                    }
+            }
+            bvh4.resize(next4);
+            bvh_flags.assign(next4, 0);
+            for (int t : queue4) {
+                int kids[4];
+                const int n = kids_of(t, kids);
+                DBvhNode4 d{};
+                uint8_t flags = 0;
+                for (int c = 0; c < 4; c++) {
+                    uint16_t lo[3] = {65535, 65535, 65535}, hi[3] = {0, 0, 0};  // unused slot: inverted box
+                    d.child[c] = RTC_NO_CHILD;
+                    if (c < n) {
+                        const BuildNode &k = b.nodes[kids[c]];
+                        for (int a = 0; a < 3; a++) lo[a] = q_down(k.b.lo[a], a), hi[a] = q_up(k.b.hi[a], a);
+                        d.child[c] = child_ref(kids[c], index4);
+                        if (paired[kids[c]]) flags |= (uint8_t)(1u << c);
+                    }
+                    d.box[3 * c + 0] = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+                    d.box[3 * c + 1] = (uint32_t)lo[2] | ((uint32_t)hi[0] << 16);
+                    d.box[3 * c + 2] = (uint32_t)hi[1] | ((uint32_t)hi[2] << 16);
+                }
+                bvh_flags[index4[t]] = flags;
+                bvh4[index4[t]] = d;
+            }
         }
     }
     bvh_prims = order;
@@ -703,7 +770,11 @@ int Scene::upload(int dev, DeviceReplica &rep) {
     if ((rc = upload_vec(rep, lights, dscene.lights))) return rc;
     if ((rc = upload_vec(rep, dpatterns, dscene.patterns))) return rc;
     if (quantized_nodes) {
-        if ((rc = upload_vec(rep, bvh_q, dscene.bvh_q))) return rc;
+        if (RTC_BVH4) {
+            if ((rc = upload_vec(rep, bvh4, dscene.bvh4))) return rc;
+        } else {
+            if ((rc = upload_vec(rep, bvh_q, dscene.bvh_q))) return rc;
+        }
     } else {
         if ((rc = upload_vec(rep, bvh, dscene.bvh))) return rc;
     }
@@ -756,7 +827,7 @@ int Scene::upload(int dev, DeviceReplica &rep) {
     dscene.n_bounded = (int32_t)bvh_prims.size();
     dscene.n_prims = (int32_t)prims.size();
     dscene.n_unbounded = (int32_t)unbounded.size();
-    dscene.n_bvh_nodes = (int32_t)bvh.size();
+    dscene.n_bvh_nodes = (int32_t)((quantized_nodes && RTC_BVH4) ? bvh4.size() : bvh.size());
     dscene.n_lights = (int32_t)lights.size();
     dscene.n_materials = (int32_t)dmaterials.size();
     dscene.all_cast_shadow = 1;

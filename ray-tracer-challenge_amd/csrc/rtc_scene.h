@@ -82,7 +82,8 @@ struct Scene {
     std::vector<DTri> tris;
     std::vector<DMaterial> dmaterials;
     std::vector<DPattern> dpatterns;
-    std::vector<DBvhNode> bvh;     // f32 nodes; bvh_q holds the same tree quantised when quantized_nodes
+    std::vector<DBvhNode> bvh;     // binary f32 nodes; large hierarchies are uploaded as bvh4 instead (quantized_nodes)
+    std::vector<DBvhNode4> bvh4;
     std::vector<DBvhNodeQ> bvh_q;
     bool quantized_nodes = false;
     std::vector<uint8_t> bvh_flags;

@@ -130,6 +130,21 @@ struct DBvhNodeQ {
     uint16_t rmin[3], rmax[3];
     int32_t left, right;
 };
+// Large hierarchies, round 2: FOUR children per node (the binary SAH tree with every other level folded into its
+// parent), 64 B = one fetch per TWO levels of the binary tree.  Traversal of a large scene is a chain of dependent
+// cache misses (waves wait on memory for more than half of their life with 3 waves per SIMD): halving the length of
+// that chain is worth more than the few extra box tests of a wider node now that a box test is 20 f32 instructions.
+//   box[3c .. 3c+2]  child c: min.x | min.y << 16,  min.z | max.x << 16,  max.y | max.z << 16   (cell indices, outward)
+//   child[c]         as above; an unused slot holds RTC_NO_CHILD and an inverted box
+#ifndef RTC_BVH4
+#define RTC_BVH4 0  // 1: large hierarchies are traversed four wide (DBvhNode4), 0: binary (DBvhNodeQ)
+#endif
+struct DBvhNode4 {
+    uint32_t box[12];
+    int32_t child[4];
+};
+static_assert(sizeof(DBvhNode4) == 64, "DBvhNode4 is one 64-byte fetch");
+#define RTC_NO_CHILD ((int32_t)0x80000000)
 
 struct DCamera {
     double inv[12];
@@ -142,8 +157,9 @@ struct DScene {
     // The struct is the kernel argument: ~100 SGPRs fetched in blocks of up to 16 registers, and what does not
     // fit is parked in VGPR lanes and brought back a whole block at a time.  The first 64 bytes are therefore
     // exactly what the traversal loop dereferences, so that this block stays resident.
-    const DBvhNodeQ *bvh_q;     // one of bvh / bvh_q is set (quantized_nodes)
-    const uint8_t *node_flags;  // per node: bit 0 / 1 = the left / right subtree holds "paired" primitives only
+    const DBvhNode4 *bvh4;      // quantized_nodes: bvh4 (RTC_BVH4) or bvh_q is set, else bvh
+    const DBvhNodeQ *bvh_q;
+    const uint8_t *node_flags;  // per node: bit c = the subtree of child c holds "paired" primitives only
     const DLeaf *leaves;        // [0, n_unbounded): primitives tested for every ray; then the BVH leaves' runs
     const DLeafS *leaves_s;     // compact records of sphere-only leaf runs (large hierarchies)
     const DBvhNode *bvh;
@@ -161,7 +177,7 @@ struct DScene {
     int32_t all_cast_shadow;  // 1 if every material has casts_shadow: shadow rays may stop at any hit
     int32_t any_pattern;
     int32_t any_group;        // 1 if some primitive sits inside a group (ancestor transforms exist)
-    int32_t quantized_nodes;  // 1: bvh_q, 0: bvh
+    int32_t quantized_nodes;  // 1: bvh4, 0: bvh
     int32_t pad0;
     double q_org[3], q_cell[3]; // box plane along axis a = q_org[a] + q * q_cell[a]
     double root_min[3], root_max[3];

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liborc_oracle.so")
 
-SPHERE, PLANE, CUBE, CYLINDER, CONE, TRIANGLE, SMOOTH_TRIANGLE, GROUP, TEST_SHAPE = range(9)
+SPHERE, PLANE, CUBE, CYLINDER, CONE, TRIANGLE, SMOOTH_TRIANGLE, GROUP, TEST_SHAPE, CSG = range(10)
+CSG_UNION, CSG_INTERSECTION, CSG_DIFFERENCE = range(3)
 PAT_STRIPE, PAT_GRADIENT, PAT_RING, PAT_CHECKER, PAT_RADIAL, PAT_SOLID, PAT_BLENDED, PAT_TEST = range(8)
 OK, ERR_NON_INVERTIBLE, ERR_INVALID = 0, 1, 2
 COMPS_LEN = 27
@@ -82,6 +83,10 @@ def lib():
     L.orc_add_area_light.argtypes = [C.c_void_p, PD, PD, C.c_uint32, PD, C.c_uint32, PD]
     L.orc_set_camera.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, PD]
     L.orc_shape_set_material.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.orc_add_csg.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.orc_csg_intersection_allowed.argtypes = [C.c_int] * 4
+    L.orc_csg_filter.argtypes = [C.c_void_p, C.c_int, C.c_int, PD, PI32, PI32]
+    L.orc_shape_includes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.orc_render.argtypes = [C.c_void_p, C.c_int, PD, C.POINTER(Stats)]
     L.orc_render_subset.argtypes = [
         C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, PD, C.POINTER(Stats)]
@@ -280,6 +285,25 @@ class World:
                 material)
         assert idx >= 0, idx
         return idx
+
+    def csg(self, operation, parent=-1):
+        """Csg node (shape.rs:2166-2184): add left, then right, with parent=<the returned index>"""
+        idx = self.L.orc_add_csg(self.h, parent, operation)
+        assert idx >= 0, idx
+        return idx
+
+    def csg_filter(self, csg, xs):
+        """Csg::filter_intersections over [(t, shape), ...] -> indices of the records that pass"""
+        n = len(xs)
+        ts = (C.c_double * n)(*[float(x[0]) for x in xs])
+        sh = (C.c_int * n)(*[int(x[1]) for x in xs])
+        kept = (C.c_int * max(n, 1))()
+        m = self.L.orc_csg_filter(self.h, csg, n, ts, sh, kept)
+        assert m >= 0, m
+        return list(kept[:m])
+
+    def includes(self, shape, obj):
+        return bool(self.L.orc_shape_includes(self.h, shape, obj))
 
     def set_material(self, shape, material):
         assert self.L.orc_shape_set_material(self.h, shape, material) == OK

@@ -635,3 +635,65 @@ def test_scale_and_clamp():
     # canvas.rs:86-89 + Rust `as u8` saturation
     assert orc.scale_and_clamp(1.5) == 255 and orc.scale_and_clamp(-0.5) == 0 and orc.scale_and_clamp(0.5) == 128
     assert orc.scale_and_clamp(float("nan")) == 0
+
+
+# ----------------------------------------------------------------------------- shape.rs:2146-2411 (csg)
+
+def test_csg_operation_rule():
+    # shape.rs:2322-2355
+    U, I, D = orc.CSG_UNION, orc.CSG_INTERSECTION, orc.CSG_DIFFERENCE
+    examples = [
+        (U, 1, 1, 1, 0), (U, 1, 1, 0, 1), (U, 1, 0, 1, 0), (U, 1, 0, 0, 1),
+        (U, 0, 1, 1, 0), (U, 0, 1, 0, 0), (U, 0, 0, 1, 1), (U, 0, 0, 0, 1),
+        (I, 1, 1, 1, 1), (I, 1, 1, 0, 0), (I, 1, 0, 1, 1), (I, 1, 0, 0, 0),
+        (I, 0, 1, 1, 1), (I, 0, 1, 0, 1), (I, 0, 0, 1, 0), (I, 0, 0, 0, 0),
+        (D, 1, 1, 1, 0), (D, 1, 1, 0, 1), (D, 1, 0, 1, 0), (D, 1, 0, 0, 1),
+        (D, 0, 1, 1, 1), (D, 0, 1, 0, 1), (D, 0, 0, 1, 0), (D, 0, 0, 0, 0),
+    ]
+    for op, lhit, inl, inr, expected in examples:
+        assert bool(orc.lib().orc_csg_intersection_allowed(op, lhit, inl, inr)) == bool(expected)
+
+
+def test_csg_filter_list_of_intersections():
+    # shape.rs:2357-2382: sphere (left) and cube (right), records at t = 1 (s1), 2 (s2), 3 (s1), 4 (s2)
+    for op, x0, x1 in ((orc.CSG_UNION, 0, 3), (orc.CSG_INTERSECTION, 1, 2), (orc.CSG_DIFFERENCE, 0, 1)):
+        w = orc.World()
+        c = w.csg(op)
+        s1 = w.shape(orc.SPHERE, parent=c)
+        s2 = w.shape(orc.CUBE, parent=c)
+        assert w.csg_filter(c, [(1, s1), (2, s2), (3, s1), (4, s2)]) == [x0, x1]
+
+
+def test_csg_create_and_includes():
+    # shape.rs:2297-2320 (left / right / parents) and the includes() rules :136-138, :2023-2030, :2278-2280
+    w = orc.World()
+    c = w.csg(orc.CSG_UNION)
+    s1 = w.shape(orc.SPHERE, parent=c)
+    g = w.shape(orc.GROUP, parent=c)
+    s2 = w.shape(orc.CUBE, parent=g)
+    inner = w.csg(orc.CSG_DIFFERENCE, parent=g)
+    s3 = w.shape(orc.SPHERE, parent=inner)
+    s4 = w.shape(orc.CONE, parent=inner)
+    other = w.shape(orc.SPHERE)
+    assert w.includes(s1, s1) and not w.includes(s1, s2)
+    assert w.includes(g, s2) and w.includes(g, s4) and not w.includes(g, s1)
+    assert w.includes(inner, s3) and w.includes(inner, s4) and not w.includes(inner, s2)
+    assert all(w.includes(c, s) for s in (s1, s2, s3, s4)) and not w.includes(c, other)
+    # a Csg has exactly a left and a right child
+    assert orc.lib().orc_add_shape(w.h, orc.SPHERE, c, orc._d16(orc.identity()), w.material(), -orc.INF, orc.INF, 0) < 0
+
+
+def test_csg_ray_misses_and_hits():
+    # shape.rs:2384-2392
+    w = orc.World()
+    c = w.csg(orc.CSG_UNION)
+    w.shape(orc.SPHERE, parent=c)
+    w.shape(orc.CUBE, parent=c)
+    assert w.local_intersect(c, (0, 2, -5), (0, 0, 1)) == []
+    # shape.rs:2394-2409: two overlapping spheres, union -> t = 4 (sphere1), 6.5 (sphere2)
+    w = orc.World()
+    c = w.csg(orc.CSG_UNION)
+    s1 = w.shape(orc.SPHERE, parent=c)
+    s2 = w.shape(orc.SPHERE, transform=orc.translation(0, 0, 0.5), parent=c)
+    xs = w.intersect(c, (0, 0, -5), (0, 0, 1))
+    assert [(x[0], x[1]) for x in xs] == [(4.0, s1), (6.5, s2)]
