@@ -203,6 +203,18 @@ int rtc_scene_check(rtc_scene *scene);
  * ascending canvas-row order (every row, including an all-black last canvas row if it is owned).
  * Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream); allocates nothing. */
 int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream);
+/* rtc_render_device for callers that cannot allocate and cannot rely on memory the library allocated for this
+ * scene's launches: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO
+ * counterpart in the reference.  Same arguments, same pixels.  The kernel's work buffer (tile counters, overflow flag,
+ * mailboxes of the end-of-frame ray exchange) is a file-scope `static __device__` array of the library's code object
+ * instead of the per-scene buffer that rtc_scene_commit allocated: RTC_STATIC_SCRATCH_BYTES per GPU, held until the
+ * process ends.  Limits: collect_stats is refused; a persistent launch whose grid would exceed
+ * RTC_STATIC_SCRATCH_WAVES resident waves is refused with RTC_ERR_INVALID (rtc_render_device switches the ray exchange
+ * off instead).  Every scene on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race -- serialise them.  The call itself makes no hipMalloc / hipFree / allocating runtime call. */
+#define RTC_STATIC_SCRATCH_WAVES 4096u
+#define RTC_STATIC_SCRATCH_BYTES (36864u + RTC_STATIC_SCRATCH_WAVES * 64u * 80u)
+int rtc_render_device_static(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream);
 /* Number of canvas rows owned by (tile_index, tile_count, tile_rows) and their canvas row numbers. */
 uint32_t rtc_local_rows(uint32_t vsize, uint32_t tile_rows, uint32_t tile_index, uint32_t tile_count);
 int rtc_local_row_map(uint32_t vsize, uint32_t tile_rows, uint32_t tile_index, uint32_t tile_count,

@@ -145,6 +145,7 @@ SYMBOLS = [
     ("rtc_scene_check", C.c_int, [C.c_void_p]),
     ("rtc_render", C.c_int, [C.c_void_p, C.POINTER(RenderOpts), PD, C.POINTER(Stats)]),
     ("rtc_render_device", C.c_int, [C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]),
+    ("rtc_render_device_static", C.c_int, [C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]),
     ("rtc_local_rows", C.c_uint32, [C.c_uint32] * 4),
     ("rtc_local_row_map", C.c_int, [C.c_uint32] * 4 + [C.POINTER(C.c_uint32), C.c_uint32]),
     ("rtc_scene_last_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),

@@ -434,6 +434,11 @@ class CompiledScene:
         o = self._opts(**kw)
         N.check(self.L.rtc_render_device(self.h, C.byref(o), C.c_void_p(device_ptr), C.c_void_p(stream)))
 
+    def render_device_static(self, device_ptr: int, stream: int = 0, **kw):
+        """rtc_render_device_static: the same launch with the library's static device array as its work buffer."""
+        o = self._opts(**kw)
+        N.check(self.L.rtc_render_device_static(self.h, C.byref(o), C.c_void_p(device_ptr), C.c_void_p(stream)))
+
     def stats(self):
         st = N.Stats()
         N.check(self.L.rtc_scene_last_stats(self.h, C.byref(st)))

@@ -369,7 +369,8 @@ static int overflow_error() {
     return RTC_ERR_OVERFLOW;
 }
 
-int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream) {
+static int render_device_common(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream,
+                                bool static_scratch_only) {
     CHECK_SCENE(scene)
     Scene &s = scene->s;
     DRenderParams p;
@@ -382,13 +383,30 @@ int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_r
     }
     DeviceReplica &r = s.reps[0];
     unsigned *work = r.d_work;
+    if (static_scratch_only) {
+        if (o.collect_stats) {
+            set_error("rtc_render_device_static does not run the counting kernel (collect_stats)");
+            return RTC_ERR_INVALID;
+        }
+        if ((rc = static_scratch(r.device, &work))) return rc;
+    }
     if (p.local_rows == 0) return RTC_OK;
     DeviceGuard guard(r.device);
     if (!guard.ok) {
         set_error("hipSetDevice(%d) failed", r.device);
         return RTC_ERR_HIP;
     }
-    return launch_on(s, r, p, o, d_rgb, work, (hipStream_t)hip_stream);
+    // (the static scratch holds mailboxes for RTC_MAX_WAVES resident waves: the static variant refuses a larger grid
+    // with a clear error where rtc_render_device switches the ray exchange off)
+    return launch_on(s, r, p, o, d_rgb, work, (hipStream_t)hip_stream, static_scratch_only);
+}
+
+int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream) {
+    return render_device_common(scene, opts, d_rgb, hip_stream, false);
+}
+
+int rtc_render_device_static(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream) {
+    return render_device_common(scene, opts, d_rgb, hip_stream, true);
 }
 
 int rtc_scene_check(rtc_scene *scene) {

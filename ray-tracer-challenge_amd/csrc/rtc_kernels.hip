@@ -23,6 +23,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <cstdlib>
 
 #include "rtc_scene.h"
@@ -55,10 +56,10 @@ RTC_FLAVOUR_BEGIN
 #ifndef RTC_NODES_PER_STEP
 #define RTC_NODES_PER_STEP 2          // BVH nodes one step may descend through
 #endif
-#define RTC_SHARDS 8u  // tile counters of the persistent grid
 #ifndef RTC_NODES4_PER_STEP
 #define RTC_NODES4_PER_STEP 1         // the same for the four-wide nodes of large hierarchies
 #endif
+#define RTC_SHARDS 8u  // tile counters of the persistent grid
 #ifndef RTC_STAY_MIN
 #define RTC_STAY_MIN 16  // waiting lanes (finished pass / free) at which a wave leaves the traversal loop to serve them
 #endif
@@ -1343,7 +1344,6 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         // reaches the hit point -- a sphere wholly before the hit toggles in and out again
                         const bool cont = T.mode == MODE_CONTAINER;
                         const unsigned flags = cont ? s.node_flags[ref] : 0u;
-                        bool hl, hr;
                         // the ray segment [lo, T.lim] in f32, rounded outward (T.lim moves when a leaf test finds a hit)
                         const float hi32 = f32_above(T.lim), lo32 = (float)lo, lim_lo32 = f32_below(T.lim);
                         if (QNODES && RTC_BVH4) {
@@ -1379,6 +1379,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         }
                         float tl, tr;
                         CNT(ST_BOX, 2);
+                        bool hl, hr;
                         int cl, cr;
                         if (QNODES) {
                             const uint4 *np = (const uint4 *)(s.bvh_q + ref);
@@ -1693,6 +1694,38 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
             if (lane == 0 && v) atomicAdd(&stats[i], v);
         }
     }
+}
+
+// ---- rtc_render_device_static: the work buffer as a static device array ------------------------------------------
+// One copy per GPU, loaded with the code object and held until the process ends.  `scratch` is a host-side stand-in
+// for the symbol, not a device address: host code only ever uses the per-device pointer that hipGetSymbolAddress
+// returned (kernel argument, hipMemsetAsync).  Contents survive from call to call; what must start at zero (tile
+// counters, mailbox states) is cleared by launch_render's hipMemsetAsync before every persistent launch, and the
+// overflow flag is compared with a per-launch id, so stale values never match.
+static __device__ __align__(256) unsigned char scratch[RTC_WORK_TOTAL_BYTES];
+static_assert(RTC_WORK_TOTAL_BYTES == RTC_STATIC_SCRATCH_BYTES, "include/rtc.h states the size of the static scratch");
+static_assert(RTC_MAX_WAVES == RTC_STATIC_SCRATCH_WAVES, "include/rtc.h states the wave limit of the static scratch");
+static std::mutex g_scratch_mu;
+static unsigned *g_scratch_ptr[RTC_MAX_DEVICES];
+
+int static_scratch(int device, unsigned **out) {
+    if (device < 0 || device >= RTC_MAX_DEVICES) {
+        set_error("device %d: the static scratch is kept for devices 0..%d", device, RTC_MAX_DEVICES - 1);
+        return RTC_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        DeviceGuard guard(device);  // each GPU holds its own copy of the array at its own address
+        void *p = nullptr;
+        const hipError_t e = guard.ok ? hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) : hipErrorInvalidDevice;
+        if (e != hipSuccess || !p) {
+            set_error("hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(e));
+            return RTC_ERR_HIP;
+        }
+        g_scratch_ptr[device] = (unsigned *)p;
+    }
+    *out = g_scratch_ptr[device];
+    return RTC_OK;
 }
 
 template <class K>

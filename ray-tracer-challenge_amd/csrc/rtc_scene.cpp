@@ -866,6 +866,9 @@ int Scene::upload(int dev, DeviceReplica &rep) {
         return RTC_ERR_HIP;
     }
     rep.ev_start = a, rep.ev_stop = b;
+    // the static scratch array of rtc_render_device_static is resolved here, once per device, with the device current
+    unsigned *unused = nullptr;
+    if (int rcs = static_scratch(dev, &unused)) return rcs;
     device_bytes += rep.bytes;
     return RTC_OK;
 }

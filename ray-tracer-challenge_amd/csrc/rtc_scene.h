@@ -125,6 +125,8 @@ struct DeviceGuard {
 };
 
 #define RTC_MAX_DEVICES 64
+// rtc_kernels.hip: the file-scope static device array behind rtc_render_device_static, resolved once per device
+int static_scratch(int device, unsigned **out);
 
 
 // kernels (rtc_kernels.hip)

@@ -6,6 +6,7 @@ import math
 
 import numpy as np
 import pytest
+import torch  # before anything initialises HIP: torch brings its own copy of the runtime (the import order matters)
 
 import scene_feed as sf
 from scene_feed import rtc
@@ -27,7 +28,6 @@ def _glass(w, h, n_side):
 
 
 def _both(scene, cam, **kw):
-    import torch
     a = torch.full((cam.vsize, cam.hsize, 3), -1.0, dtype=torch.float64, device="cuda:0")
     b = torch.full((cam.vsize, cam.hsize, 3), -2.0, dtype=torch.float64, device="cuda:0")
     scene.render_device(a.data_ptr(), 0, **kw)
@@ -54,7 +54,6 @@ def test_static_scratch_entry_point_equals_render_device_twice_in_a_row():
             assert np.array_equal(a3, b3) and np.array_equal(a3, a)
         # the overflow flag lives in the shared array too: a capped launch reports, the next clean one does not
         scene, cam = scenes[1]
-        import torch
         buf = torch.zeros((cam.vsize, cam.hsize, 3), dtype=torch.float64, device="cuda:0")
         scene.render_device_static(buf.data_ptr(), 0, schedule=2, max_rays_per_pixel=6)
         with pytest.raises(rtc._native.RtcError) as e:
@@ -71,7 +70,6 @@ def test_static_scratch_entry_point_rejects_what_it_cannot_hold():
     world, cam = _glass(64, 40, 2)
     scene = cam.compile(world, device=0)
     try:
-        import torch
         buf = torch.zeros((cam.vsize, cam.hsize, 3), dtype=torch.float64, device="cuda:0")
         with pytest.raises(rtc._native.RtcError) as e:
             scene.render_device_static(buf.data_ptr(), 0, collect_stats=True)
