@@ -31,6 +31,8 @@ WORKLOADS = {
     # name: (scene file, width, height)
     "teapot_4k": ("teapot", 3840, 2160),
     "stress_4k": ("stress", 3840, 2160),  # BASELINE.json configs[4]: 100k glass/mirror spheres + teapot
+    "stress_1080p": ("stress", 1920, 1080),  # (diagnostic: how much of the 4K frame time is its tail)
+    "stress_8k": ("stress", 7680, 4320),
     "cover_4k": ("cover", 3840, 2160),
     "cover_1080p": ("cover", 1920, 1080),
     "reflective_world_1080p": ("reflective_world", 1920, 1080),
@@ -307,7 +309,7 @@ def main():
     if not args.no_extra and not distributed:
         extra = {}
         for wl in WORKLOADS:
-            if wl == args.workload or (wl == "stress_4k" and not args.extra_stress):
+            if wl == args.workload or (wl.startswith("stress") and not args.extra_stress):
                 continue
             w2, c2 = load(wl)
             s2 = c2.compile(w2, device=local_rank)

@@ -43,8 +43,10 @@ enum rtc_status {
 };
 
 /* ShapeType, shape.rs:27-38.  Triangles are added with rtc_scene_add_triangles, groups with
- * rtc_scene_begin_group/end_group.  Csg is out of scope (unreachable from YAML). */
+ * rtc_scene_begin_group/end_group, Csg nodes with rtc_scene_begin_csg/end_csg. */
 enum rtc_shape_type { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4 };
+/* CsgOp, shape.rs:2149-2154 */
+enum rtc_csg_op { RTC_CSG_UNION = 0, RTC_CSG_INTERSECTION = 1, RTC_CSG_DIFFERENCE = 2 };
 
 /* PatternType, pattern.rs:5-15 (Perturbed excluded: arithmetic lives in the un-vendored perlin_noise crate) */
 enum rtc_pattern_type {
@@ -160,6 +162,14 @@ int rtc_scene_add_pattern(rtc_scene *scene, int type, const double a[3], const d
  * triangles consult (shape.rs:1520-1532). */
 int rtc_scene_begin_group(rtc_scene *scene, const double transform[16], int32_t material_id);
 int rtc_scene_end_group(rtc_scene *scene);
+/* Csg::new(operation, left, right), shape.rs:2166-2184: the first object added after rtc_scene_begin_csg is `left`,
+ * the second `right` (analytic shapes, groups or other Csg nodes); rtc_scene_end_csg closes the node and fails with
+ * RTC_ERR_STATE unless exactly two were added.  Like the reference's Csg the node has no transformation and no
+ * material of its own.  Triangles cannot be direct children (Triangle::material() panics under a Csg parent,
+ * shape.rs:1521-1523); put them in a group.  Equal-t records of the two operands are ordered by depth-first shape
+ * index (the reference sorts them with sort_unstable_by, shape.rs:2232: unspecified). */
+int rtc_scene_begin_csg(rtc_scene *scene, int operation);
+int rtc_scene_end_csg(rtc_scene *scene);
 /* Sphere/Plane/Cube/Cylinder/Cone::new, shape.rs:179, 498, 653, 873, 1190.  minimum/maximum/closed are used
  * by cylinders and cones only. */
 int rtc_scene_add_shape(rtc_scene *scene, int type, const double transform[16], uint32_t material_id,
@@ -237,9 +247,9 @@ int rtc_scene_get_info(rtc_scene *scene, rtc_scene_info *out);
 /* The builder tree as the reference would hold it (World.objects and Group::children order), for loaders'
  * callers and tests.  Items are numbered in insertion order. */
 typedef struct rtc_item_info {
-    int32_t kind;        /* 0 = group, 1 = analytic shape, 2 = run of triangles */
-    int32_t parent;      /* enclosing group's item index, -1 = member of World.objects */
-    int32_t shape_type;  /* rtc_shape_type (kind 1) */
+    int32_t kind;        /* 0 = group, 1 = analytic shape, 2 = run of triangles, 3 = Csg node */
+    int32_t parent;      /* enclosing group's / Csg's item index, -1 = member of World.objects */
+    int32_t shape_type;  /* rtc_shape_type (kind 1), rtc_csg_op (kind 3) */
     int32_t material_id; /* -1 = none */
     uint32_t n_children; /* kind 0 */
     uint32_t n_triangles; /* kind 2 */

@@ -5,7 +5,8 @@ include/rtc.h); this package is the thin host-side mirror.  There is no CPU rend
 """
 from . import _native, parallel, stress_scene
 from ._native import NonInvertibleMatrix, RtcError
-from .api import (AreaLight, BlendedPattern, Camera, Canvas, CheckerPattern, CompiledScene, Cone, Cube, Cylinder,
+from .api import (AreaLight, BlendedPattern, Camera, Canvas, CheckerPattern, CompiledScene, Cone, Csg, CsgDifference,
+                  CsgIntersection, CsgUnion, Cube, Cylinder,
                   GradientPattern, Group, Material, Matrix, NativeScene, Pattern, Plane, PointLight, RadialGradientPattern,
                   RingPattern, Shape, SmoothTriangle, SolidPattern, Sphere, StripePattern, TestPattern, Triangle,
                   TriangleMesh, World, canvas_to_ppm, compute_view_transformation, glass_sphere)

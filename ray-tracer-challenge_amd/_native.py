@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("RTC_AMD_LIB") or os.path.join(_HERE, "librtc_amd.so")
 
 OK, ERR_NON_INVERTIBLE, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_IO, ERR_PARSE, ERR_OVERFLOW = range(9)
 SPHERE, PLANE, CUBE, CYLINDER, CONE = range(5)
+CSG_UNION, CSG_INTERSECTION, CSG_DIFFERENCE = range(3)
 PAT_STRIPE, PAT_GRADIENT, PAT_RING, PAT_CHECKER, PAT_RADIAL, PAT_SOLID, PAT_BLENDED, PAT_TEST = range(8)
 
 PD = C.POINTER(C.c_double)
@@ -138,6 +139,8 @@ SYMBOLS = [
      [C.c_void_p, C.c_int, PD, PD, C.c_int32, C.c_int32, PD, C.POINTER(C.c_uint32)]),
     ("rtc_scene_begin_group", C.c_int, [C.c_void_p, PD, C.c_int32]),
     ("rtc_scene_end_group", C.c_int, [C.c_void_p]),
+    ("rtc_scene_begin_csg", C.c_int, [C.c_void_p, C.c_int]),
+    ("rtc_scene_end_csg", C.c_int, [C.c_void_p]),
     ("rtc_scene_add_shape", C.c_int, [C.c_void_p, C.c_int, PD, C.c_uint32, C.c_double, C.c_double, C.c_int]),
     ("rtc_scene_add_triangles", C.c_int, [C.c_void_p, C.c_size_t, PD, PD, C.c_uint32]),
     ("rtc_scene_commit", C.c_int, [C.c_void_p, C.c_int]),

@@ -255,6 +255,26 @@ class Group:
         return self
 
 
+@dataclass
+class Csg:
+    """shape.rs:2156-2184: Csg::new(operation, left, right); operands are shapes, groups or other Csg nodes"""
+    operation: int
+    left: object
+    right: object
+
+
+def CsgUnion(left, right):
+    return Csg(N.CSG_UNION, left, right)
+
+
+def CsgIntersection(left, right):
+    return Csg(N.CSG_INTERSECTION, left, right)
+
+
+def CsgDifference(left, right):
+    return Csg(N.CSG_DIFFERENCE, left, right)
+
+
 # ----------------------------------------------------------------------------- lights (light.rs)
 
 @dataclass
@@ -371,6 +391,11 @@ class CompiledScene:
             for c in obj.children:
                 self._add(c)
             N.check(L.rtc_scene_end_group(h))
+        elif isinstance(obj, Csg):
+            N.check(L.rtc_scene_begin_csg(h, obj.operation))
+            self._add(obj.left)
+            self._add(obj.right)
+            N.check(L.rtc_scene_end_csg(h))
         elif isinstance(obj, Shape):
             N.check(L.rtc_scene_add_shape(h, obj.kind, _d16(obj.transformation.m), self._material(obj.material),
                                           obj.minimum, obj.maximum, int(obj.closed)))

@@ -71,6 +71,8 @@ void rtc_view_transform(const double from[3], const double to[3], const double u
 rtc_scene *rtc_scene_create(void) { return new (std::nothrow) rtc_scene(); }
 void rtc_scene_destroy(rtc_scene *scene) { delete scene; }
 
+static int check_parent(Scene &s, bool triangles);
+
 #define CHECK_SCENE(sc)                      \
     if (!(sc)) {                             \
         set_error("scene handle is NULL");   \
@@ -159,6 +161,7 @@ int rtc_scene_add_pattern(rtc_scene *scene, int type, const double a[3], const d
 
 int rtc_scene_begin_group(rtc_scene *scene, const double transform[16], int32_t material_id) {
     CHECK_OPEN(scene)
+    if (int rc = check_parent(scene->s, false)) return rc;
     Item it;
     it.kind = Item::GROUP;
     it.transform = transform ? Mat4::from16(transform) : Mat4::identity();
@@ -170,7 +173,7 @@ int rtc_scene_begin_group(rtc_scene *scene, const double transform[16], int32_t 
 
 int rtc_scene_end_group(rtc_scene *scene) {
     CHECK_OPEN(scene)
-    if (scene->s.open_groups.empty()) {
+    if (scene->s.open_groups.empty() || scene->s.items[scene->s.open_groups.back()].kind != Item::GROUP) {
         set_error("rtc_scene_end_group without a matching rtc_scene_begin_group");
         return RTC_ERR_STATE;
     }
@@ -178,9 +181,58 @@ int rtc_scene_end_group(rtc_scene *scene) {
     return RTC_OK;
 }
 
+// a Csg takes exactly a left and a right operand, and no bare triangles
+static int check_parent(Scene &s, bool triangles) {
+    if (s.open_groups.empty()) return RTC_OK;
+    const Item &parent = s.items[s.open_groups.back()];
+    if (parent.kind != Item::CSG) return RTC_OK;
+    if (triangles) {
+        set_error("triangles cannot be direct children of a Csg (Triangle::material() panics, shape.rs:1521-1523): "
+                  "put them in a group");
+        return RTC_ERR_INVALID;
+    }
+    if (parent.children.size() >= 2) {
+        set_error("a Csg takes exactly a left and a right shape (Csg::new, shape.rs:2166)");
+        return RTC_ERR_STATE;
+    }
+    return RTC_OK;
+}
+
+int rtc_scene_begin_csg(rtc_scene *scene, int operation) {
+    CHECK_OPEN(scene)
+    if (operation < RTC_CSG_UNION || operation > RTC_CSG_DIFFERENCE) {
+        set_error("unknown Csg operation %d", operation);
+        return RTC_ERR_INVALID;
+    }
+    if (int rc = check_parent(scene->s, false)) return rc;
+    Item it;
+    it.kind = Item::CSG;
+    it.type = operation;
+    const int idx = scene->s.add_item(std::move(it));
+    scene->s.open_groups.push_back(idx);
+    return RTC_OK;
+}
+
+int rtc_scene_end_csg(rtc_scene *scene) {
+    CHECK_OPEN(scene)
+    Scene &s = scene->s;
+    if (s.open_groups.empty() || s.items[s.open_groups.back()].kind != Item::CSG) {
+        set_error("rtc_scene_end_csg without a matching rtc_scene_begin_csg");
+        return RTC_ERR_STATE;
+    }
+    if (s.items[s.open_groups.back()].children.size() != 2) {
+        set_error("a Csg takes exactly a left and a right shape (Csg::new, shape.rs:2166), %zu added",
+                  s.items[s.open_groups.back()].children.size());
+        return RTC_ERR_STATE;
+    }
+    s.open_groups.pop_back();
+    return RTC_OK;
+}
+
 int rtc_scene_add_shape(rtc_scene *scene, int type, const double transform[16], uint32_t material_id,
                         double minimum, double maximum, int closed) {
     CHECK_OPEN(scene)
+    if (int rc = check_parent(scene->s, false)) return rc;
     if (type < RTC_SPHERE || type > RTC_CONE) {
         set_error("unknown shape type %d", type);
         return RTC_ERR_INVALID;
@@ -199,6 +251,7 @@ int rtc_scene_add_triangles(rtc_scene *scene, size_t n, const double *points, co
                             uint32_t material_id) {
     CHECK_OPEN(scene)
     if (n == 0) return RTC_OK;
+    if (int rc = check_parent(scene->s, true)) return rc;
     if (!points) {
         set_error("points is NULL");
         return RTC_ERR_INVALID;
@@ -679,7 +732,7 @@ int rtc_scene_get_item(rtc_scene *scene, uint32_t item, rtc_item_info *out) {
     }
     const Item &it = scene->s.items[item];
     std::memset(out, 0, sizeof *out);
-    out->kind = it.kind == Item::GROUP ? 0 : it.kind == Item::SHAPE ? 1 : 2;
+    out->kind = it.kind == Item::GROUP ? 0 : it.kind == Item::SHAPE ? 1 : it.kind == Item::TRIANGLES ? 2 : 3;
     out->parent = it.parent;
     out->shape_type = it.type;
     out->material_id = it.material;

@@ -61,7 +61,7 @@ RTC_FLAVOUR_BEGIN
 #endif
 #define RTC_SHARDS 8u  // tile counters of the persistent grid
 #ifndef RTC_STAY_MIN
-#define RTC_STAY_MIN 16  // waiting lanes (finished pass / free) at which a wave leaves the traversal loop to serve them
+#define RTC_STAY_MIN 24  // waiting lanes (finished pass / free) at which a wave leaves the traversal loop to serve them
 #endif
 #ifndef RTC_REFILL_MIN
 #define RTC_REFILL_MIN 1  // free lanes needed before a wave assigns new pixels
@@ -216,6 +216,26 @@ DEV void visit_uv(Trace &T, int pi, double t, double u, double v) {
         T.b = v;
     }
 }
+// What one primitive test yields when its records are wanted as a list (Csg, below): at most four (cylinder / cone:
+// two on the side, two on the caps), in the order the reference pushes them.
+struct Collect {
+    double t0, t1, t2, t3;
+    double u, v;
+    int n;
+};
+DEV void visit(Collect &C, int, double t) {
+    if (C.n == 0) C.t0 = t;
+    else if (C.n == 1) C.t1 = t;
+    else if (C.n == 2) C.t2 = t;
+    else C.t3 = t;
+    C.n++;
+}
+DEV void visit_uv(Collect &C, int pi, double t, double u, double v) {
+    C.u = u, C.v = v;
+    visit(C, pi, t);
+}
+DEV void end_prim(Collect &, int) {}
+
 DEV void end_prim(Trace &T, int pi) {
     if (T.mode == MODE_CONTAINER) {
         if (T.n & 1) {
@@ -236,7 +256,8 @@ DEV void end_prim(Trace &T, int pi) {
 // ---------------------------------------------------------------------------------------------
 
 // shape.rs:218-239
-DEV void isect_sphere(const Ray &r, Trace &T, int pi) {
+template <class TR>
+DEV void isect_sphere(const Ray &r, TR &T, int pi) {
     const V3 s2r = r.o - mk(0., 0., 0.);
     const double a = dot(r.d, r.d);
     const double b = 2. * dot(r.d, s2r);
@@ -262,7 +283,8 @@ DEV void cube_axis(double origin, double direction, double &tmin, double &tmax) 
     tmin = a, tmax = b;
 }
 // shape.rs:665-704
-DEV void isect_cube(const Ray &r, Trace &T, int pi) {
+template <class TR>
+DEV void isect_cube(const Ray &r, TR &T, int pi) {
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double xmin, xmax, ymin, ymax, zmin, zmax;
     cube_axis(r.o.x, r.d.x, xmin, xmax);
@@ -285,7 +307,8 @@ DEV bool check_cap(const Ray &r, double t, double radius) {
 }
 
 // shape.rs:895-959
-DEV void isect_cylinder(const Ray &r, double minimum, double maximum, int closed, Trace &T, int pi) {
+template <class TR>
+DEV void isect_cylinder(const Ray &r, double minimum, double maximum, int closed, TR &T, int pi) {
     const double a = r.d.x * r.d.x + r.d.z * r.d.z;
     if (!approx_zero(a)) {
         const double b = 2. * r.o.x * r.d.x + 2. * r.o.z * r.d.z;
@@ -314,7 +337,8 @@ DEV void isect_cylinder(const Ray &r, double minimum, double maximum, int closed
 }
 
 // shape.rs:1212-1281 (Q8)
-DEV void isect_cone(const Ray &r, double minimum, double maximum, int closed, Trace &T, int pi) {
+template <class TR>
+DEV void isect_cone(const Ray &r, double minimum, double maximum, int closed, TR &T, int pi) {
     const double a = r.d.x * r.d.x - r.d.y * r.d.y + r.d.z * r.d.z;
     const double b = 2. * r.o.x * r.d.x - 2. * r.o.y * r.d.y + 2. * r.o.z * r.d.z;
     const double c = r.o.x * r.o.x - r.o.y * r.o.y + r.o.z * r.o.z;
@@ -349,8 +373,8 @@ DEV void isect_cone(const Ray &r, double minimum, double maximum, int closed, Tr
 }
 
 // shape.rs:1479-1502 == 1712-1735; a = p1, e1, e2
-template <class P>
-DEV void isect_triangle(const Ray &r, P a, Trace &T, int pi) {
+template <class P, class TR>
+DEV void isect_triangle(const Ray &r, P a, TR &T, int pi) {
     const V3 p1 = mk(a[0], a[1], a[2]), e1 = mk(a[3], a[4], a[5]), e2 = mk(a[6], a[7], a[8]);
     const V3 dce2 = cross(r.d, e2);
     const double det = dot(e1, dce2);
@@ -369,8 +393,8 @@ DEV void isect_triangle(const Ray &r, P a, Trace &T, int pi) {
 // shapes): Shape::intersect = ray.transform(inverse(T_own)) + local_intersect (e.g. shape.rs:254-258).  A plane
 // only ever reads the y components of the object-space ray, so only row 1 of the product is formed (the
 // arithmetic of that row is unchanged).
-template <class Leaf>
-DEV void isect_leaf(const Leaf &L, const Ray &r, Trace &T) {
+template <class Leaf, class TR>
+DEV void isect_leaf(const Leaf &L, const Ray &r, TR &T) {
     const int pi = L.prim;
     const auto *m = L.a;  // keeps the record's address space (constant for the lockstep list)
     switch (L.type) {
@@ -395,13 +419,13 @@ DEV void isect_leaf(const Leaf &L, const Ray &r, Trace &T) {
     case PT_CYLINDER: {
         Ray q;
         q.o = xf_point(m, r.o), q.d = xf_vector(m, r.d);
-        isect_cylinder(q, L.minimum, L.maximum, L.closed, T, pi);
+        isect_cylinder(q, L.minimum, L.maximum, L.closed & 1, T, pi);
         break;
     }
     case PT_CONE: {
         Ray q;
         q.o = xf_point(m, r.o), q.d = xf_vector(m, r.d);
-        isect_cone(q, L.minimum, L.maximum, L.closed, T, pi);
+        isect_cone(q, L.minimum, L.maximum, L.closed & 1, T, pi);
         break;
     }
     default: isect_triangle(r, m, T, pi); break;
@@ -597,6 +621,25 @@ DEV double safe_rcp(double d) {
     return copysign(a, d);
 }
 
+#ifndef RTC_PREFETCH
+#define RTC_PREFETCH 0
+#endif
+#ifndef RTC_BRANCHFREE
+#define RTC_BRANCHFREE 1  // the traversal's exchange with its stack as selects around LDS accesses (0: branches, round 1)
+#endif
+// first line of the record a child reference of a quantised binary node points at: another node, or the first
+// primitive record of a leaf run
+DEV const char *child_line(const DScene &s, int ref) {
+    if (ref >= 0) return (const char *)(s.bvh_q + ref);
+#if RTC_PREFETCH >= 2
+    const int first = (~ref) >> 3;
+    return (first & RTC_LEAF_COMPACT) ? (const char *)(s.leaves_s + (first & (RTC_LEAF_COMPACT - 1)))
+                                      : (const char *)(s.leaves + first);
+#else
+    return (const char *)s.bvh_q;  // (leaf runs are not requested ahead: the root node's line is always cached)
+#endif
+}
+
 struct Counters {
     unsigned long long c[ST_COUNT];
 };
@@ -635,6 +678,80 @@ DEV Ray through_ancestors(const DScene &s, int off, int len, Ray r) {
         r = q;
     }
     return r;
+}
+
+// ---- Csg (shape.rs:2146-2291) ----------------------------------------------------------------------------------------
+// Csg::intersection_allowed, shape.rs:2186-2197
+DEV bool csg_allowed(int op, bool left_hit, bool in_left, bool in_right) {
+    if (op == RTC_CSG_UNION) return left_hit ? !in_right : !in_left;
+    if (op == RTC_CSG_INTERSECTION) return left_hit ? in_right : in_left;
+    return left_hit ? !in_right : in_left;  // Difference
+}
+struct CsgRec {
+    double t, u, v;
+    int leaf;  // relative to the tree's first primitive
+};
+// One whole Csg tree against the world-space ray.  Csg::local_intersect (shape.rs:2227-2235) concatenates the records
+// of its operands, sorts them and keeps what filter_intersections (shape.rs:2203-2225) lets through; a parent Csg sees
+// only what its operands kept.  Here: every leaf of the tree is tested once (its DLeaf record carries the whole chain
+// of transforms from world space: enclosing groups, the Csg nodes' identities, inner groups), the records go into one
+// list sorted by (t in total_cmp order, leaf) -- a sub-list of a sorted list is sorted, so one sort serves every node --
+// and the nodes' filters run bottom-up over a mask of surviving records.  The survivors then enter the pass's fold
+// exactly like the records of any other primitive (they keep their own primitive's identity: containers, tie order).
+// Returns false when the ray collected more than RTC_CSG_MAX_RECORDS records.
+DEV bool isect_csg(const DScene &s, int tree, const Ray &ray, Trace &T) {
+    const DCsgRoot root = s.csg_roots[tree];
+    CsgRec recs[RTC_CSG_MAX_RECORDS];
+    int n = 0;
+    bool ok = true;
+    for (int k = 0; k < root.n_prims; k++) {
+        const DLeaf &L = s.leaves_all[root.prim_first + k];
+        Ray r = ray;
+        if (L.anc_len > 0) r = through_ancestors(s, L.anc_off, L.anc_len, ray);
+        Collect C;
+        C.t0 = C.t1 = C.t2 = C.t3 = 0., C.u = C.v = 0., C.n = 0;
+        isect_leaf(L, r, C);
+        for (int j = 0; j < C.n && j < 4; j++) {
+            const double t = j == 0 ? C.t0 : j == 1 ? C.t1 : j == 2 ? C.t2 : C.t3;
+            if (n == RTC_CSG_MAX_RECORDS) {
+                ok = false;
+                break;
+            }
+            // insertion into the sorted list: records of one leaf arrive in the reference's push order and equal keys
+            // keep their arrival order (leaves are visited in depth-first order, so ties fall by leaf index)
+            const long long key = total_key(t);
+            int i = n;
+            while (i > 0 && total_key(recs[i - 1].t) > key) {
+                recs[i] = recs[i - 1];
+                i--;
+            }
+            recs[i].t = t, recs[i].u = C.u, recs[i].v = C.v, recs[i].leaf = k;
+            n++;
+        }
+    }
+    unsigned long long alive = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    for (int q = 0; q < root.n_nodes; q++) {
+        const DCsgNode nd = s.csg_nodes[root.node_first + q];
+        bool in_left = false, in_right = false;
+        for (int i = 0; i < n; i++) {
+            if (!((alive >> i) & 1ull)) continue;
+            const int leaf = recs[i].leaf;
+            const bool left_hit = leaf >= nd.l_first && leaf < nd.l_first + nd.l_count;  // self.left.includes(object)
+            const bool right_hit = leaf >= nd.r_first && leaf < nd.r_first + nd.r_count;
+            if (!left_hit && !right_hit) continue;  // a record of another part of the tree
+            if (!csg_allowed(nd.op, left_hit, in_left, in_right)) alive &= ~(1ull << i);
+            if (left_hit)
+                in_left = !in_left;
+            else
+                in_right = !in_right;
+        }
+    }
+    for (int k = 0; k < root.n_prims; k++) {
+        for (int i = 0; i < n; i++)
+            if (((alive >> i) & 1ull) && recs[i].leaf == k) visit_uv(T, root.prim_first + k, recs[i].t, recs[i].u, recs[i].v);
+        end_prim(T, root.prim_first + k);
+    }
+    return ok;
 }
 
 // Values that are only touched between intersection passes (the shading context of the current hit and the
@@ -835,6 +952,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     // ---- BVH traversal state of the pass in flight (resumable) ----
     bool in_pass = false;
     int pos = 0, end = 0, sb = 0, cur = RTC_NO_NODE;
+#if RTC_PREFETCH
+    unsigned pf0 = 0, pf1 = 0;  // words of the records requested ahead of time (never used, see the node visit)
+#endif
     SlabRay slab_ray;  // this pass's ray in the slab test's f32 form (persists with the traversal)
     slab_ray.ax = slab_ray.ay = slab_ray.az = 0.f;
     slab_ray.bx = slab_ray.by = slab_ray.bz = (f32x2){0.f, 0.f};
@@ -1190,6 +1310,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     }
                     r = u_ray;
                 }
+                if (PATTERNS && (L.closed & RTC_LEAF_IN_CSG)) continue;  // (brute-force list: reached through its tree)
+                if (PATTERNS && L.type == PT_CSG) {
+                    if (!(any_hit && T.prim >= 0) && !isect_csg(s, L.anc_off, ray, T)) flag_overflow();
+                    continue;
+                }
                 if (!(any_hit && T.prim >= 0)) {
                     CNT(ST_XFORM, L.type < PT_TRIANGLE ? 1 : 0);  // the shape's own Ray::transform
                     CNT(ST_PRIM0 + L.type, 1);
@@ -1309,6 +1434,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     }
                     if (at_leaf) {
                         const DLeaf &L = s.leaves[pos++];
+                        if (PATTERNS && L.type == PT_CSG) {
+                            if (!isect_csg(s, L.anc_off, ray, T)) flag_overflow();
+                            if (any_hit && T.prim >= 0) in_pass = false;
+                            continue;
+                        }
                         // Ray::transform down the ancestor chain, root first (shape.rs:2035).  Primitives of one
                         // group share it: the ray in group space is cached per lane.
                         Ray r = ray;
@@ -1337,15 +1467,28 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     // ---- the node in hand, or the next one from the stack (whose bottom entry is RTC_NO_NODE: popping
                     // it ends the pass, so an empty stack needs no test of its own) ----
                     int ref = cur;
+#if RTC_BRANCHFREE
+                    // (the usual case -- every entry concerned sits in the LDS part of the stack -- is served without
+                    // a branch: the top of the stack is read whether or not it will be popped, selects do the rest)
+                    if (sb <= RTC_LDS_STACK) {
+                        const int top = stack[(sb - 1) * RTC_WAVE];
+                        const bool pop = ref == RTC_NO_NODE;
+                        ref = pop ? top : ref;
+                        sb -= pop ? 1 : 0;
+                    } else if (ref == RTC_NO_NODE)
+                        RTC_POP(ref);
+#else
                     if (ref == RTC_NO_NODE) RTC_POP(ref);
+#endif
                     // descend until a leaf is reached (bounded: the check above runs again after a few nodes)
+                    // the ray segment [lo, T.lim] in f32, rounded outward (T.lim only moves when a leaf test finds a hit,
+                    // never between the node visits of one step)
+                    const float hi32 = f32_above(T.lim), lo32 = (float)lo, lim_lo32 = f32_below(T.lim);
                     for (int d = 0; d < ((QNODES && RTC_BVH4) ? RTC_NODES4_PER_STEP : RTC_NODES_PER_STEP) && ref >= 0; d++) {
                         // containers pass: a subtree of paired primitives (spheres) matters only where its box
                         // reaches the hit point -- a sphere wholly before the hit toggles in and out again
                         const bool cont = T.mode == MODE_CONTAINER;
                         const unsigned flags = cont ? s.node_flags[ref] : 0u;
-                        // the ray segment [lo, T.lim] in f32, rounded outward (T.lim moves when a leaf test finds a hit)
-                        const float hi32 = f32_above(T.lim), lo32 = (float)lo, lim_lo32 = f32_below(T.lim);
                         if (QNODES && RTC_BVH4) {
                             // ---- four children per node (DBvhNode4): one 64-byte fetch per two levels of the binary tree ----
                             CNT(ST_BOX, 4);
@@ -1393,6 +1536,20 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                             const uint4 w0 = np[0], w1 = np[1];  // both halves requested before either is used
 #endif
                             __builtin_amdgcn_sched_barrier(0);
+#if RTC_PREFETCH
+                            // Both children's records are requested the moment their references arrive, while this
+                            // node's boxes are still being tested: whichever child is visited next (now or from the
+                            // stack) then finds its line on the way or in the cache.  The words loaded are never used;
+                            // they are "consumed" one visit later, when the wait for that visit's own node has covered
+                            // them anyway (vector loads return in order).
+                            asm volatile("" ::"v"(pf0), "v"(pf1));
+                            {
+                                const int c0 = (int)w1.z, c1 = (int)w1.w;
+                                const char *a0 = child_line(s, c0), *a1 = child_line(s, c1);
+                                pf0 = *(const unsigned *)a0;
+                                pf1 = *(const unsigned *)a1;
+                            }
+#endif
                             hl = slab32_q(w0.x, w0.y, w0.z, slab_ray, (flags & 1u) ? lim_lo32 : lo32, hi32, tl);
                             hr = slab32_q(w0.w, w1.x, w1.y, slab_ray, (flags & 2u) ? lim_lo32 : lo32, hi32, tr);
                             cl = (int)w1.z, cr = (int)w1.w;
@@ -1407,12 +1564,37 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         // near child first, the far one waits on the stack (selects, not a branch per case)
                         const bool left_first = tl <= tr;
                         const bool take_left = hl && (!hr || left_first);
+#if RTC_BRANCHFREE
+                        if (sb < RTC_LDS_STACK) {
+                            // the far child is stored above the top in any case (harmless when it is not pushed) and the
+                            // entry below it read in any case (used when both boxes are missed): two LDS operations and
+                            // five selects instead of three branches
+                            const int top = stack[(sb - 1) * RTC_WAVE];
+                            stack[sb * RTC_WAVE] = left_first ? cr : cl;
+                            const bool both = hl && hr, any = hl || hr;
+                            ref = any ? (take_left ? cl : cr) : top;
+                            sb += both ? 1 : (any ? 0 : -1);
+                            continue;
+                        }
+#endif
                         if (hl && hr) RTC_PUSH(left_first ? cr : cl);
                         if (hl || hr)
                             ref = take_left ? cl : cr;
                         else
                             RTC_POP(ref);
                     }
+#if RTC_BRANCHFREE
+                    {
+                        // what the descent arrived at: another internal node (carried to the next step), the stack's
+                        // bottom entry (every subtree has been dealt with) or a leaf's run of primitive records
+                        const bool done = ref == RTC_NO_NODE, leaf = ref < 0 && !done;
+                        const int code = ~ref;
+                        pos = leaf ? (code >> 3) : pos;
+                        end = leaf ? (code >> 3) + (code & 7) + 1 : end;
+                        cur = ref >= 0 ? ref : RTC_NO_NODE;
+                        in_pass = !done;
+                    }
+#else
                     if (ref >= 0) {
                         cur = ref;  // still an internal node: carry on at the next step
                     } else if (ref == RTC_NO_NODE) {
@@ -1424,6 +1606,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         end = pos + (code & 7) + 1;
                         cur = RTC_NO_NODE;
                     }
+#endif
                 }
 #undef RTC_PUSH
 #undef RTC_POP
@@ -1807,7 +1990,7 @@ int launch_render(const DScene &scene, const DRenderParams &params_in, double *d
     unsigned long long *ds = (unsigned long long *)d_stats;
     if (collect_stats)
         launch_nodes<true, true, true>(scene, params, d_rgb, ds, d_work, n_cu, st);
-    else if (scene.any_pattern)
+    else if (scene.any_pattern || scene.any_csg)  // the variant with the rarely used features
         launch_nodes<false, true, true>(scene, params, d_rgb, ds, d_work, n_cu, st);
     else if (scene.any_group)
         launch_nodes<false, true, false>(scene, params, d_rgb, ds, d_work, n_cu, st);

@@ -143,7 +143,7 @@ static void bounds_pad(Bounds &b) {
 int Scene::flatten() {
     xforms.clear(), xform_fwd.clear(), chains.clear(), prims.clear(), tris.clear();
     prim_bounds.clear(), prim_bounded.clear(), unbounded.clear(), bvh.clear(), bvh_prims.clear();
-    prim_anc_id.clear();
+    prim_anc_id.clear(), prim_csg.clear(), csg_roots.clear(), csg_nodes.clear();
     dmaterials.clear(), dpatterns.clear();
 
     if (!has_camera) {
@@ -206,9 +206,12 @@ int Scene::flatten() {
         int32_t chain_off, chain_len;  // chain of the parent (applies to this item before its own transform)
         int32_t group_material;        // material of the enclosing group or -1
         int32_t chain_id;
+        int32_t csg_root;              // Csg tree this item belongs to (index into csg_roots) or -1
+        int32_t marker;                // 0: visit the item; 1: the left operand of Csg `item` is complete; 2: both are
     };
     std::vector<Frame> stack;
-    for (auto it = top_level.rbegin(); it != top_level.rend(); ++it) stack.push_back({*it, 0, 0, -1, -1});
+    for (auto it = top_level.rbegin(); it != top_level.rend(); ++it) stack.push_back({*it, 0, 0, -1, -1, -1, 0});
+    std::vector<int32_t> csg_begin(items.size(), 0), csg_mid(items.size(), 0);
     int32_t next_chain_id = 0;
     const int32_t root_chain_id = next_chain_id++;
 
@@ -237,6 +240,47 @@ int Scene::flatten() {
         const Frame f = stack.back();
         stack.pop_back();
         const Item &it = items[f.item];
+        if (f.marker == 1) {
+            csg_mid[f.item] = (int32_t)prims.size();
+            continue;
+        }
+        if (f.marker == 2) {
+            // Csg::local_intersect's operands (shape.rs:2227-2235) as ranges of the tree's leaves; post-order
+            DCsgRoot &root = csg_roots[f.csg_root];
+            DCsgNode n{};
+            n.op = it.type;
+            n.l_first = csg_begin[f.item] - root.prim_first, n.l_count = csg_mid[f.item] - csg_begin[f.item];
+            n.r_first = csg_mid[f.item] - root.prim_first, n.r_count = (int32_t)prims.size() - csg_mid[f.item];
+            csg_nodes.push_back(n);
+            root.n_nodes = (int32_t)csg_nodes.size() - root.node_first;
+            root.n_prims = (int32_t)prims.size() - root.prim_first;
+            continue;
+        }
+        if (it.kind == Item::CSG) {
+            if (it.children.size() != 2) {
+                set_error("a Csg takes exactly a left and a right shape (Csg::new, shape.rs:2166), %zu given", it.children.size());
+                return RTC_ERR_INVALID;
+            }
+            // Csg::transformation() is the identity (shape.rs:2250-2252): for points and normals the node is one more
+            // level of the parent chain -- inverse(identity) and, for normals, one more normalisation (shape.rs:82-103)
+            int32_t xi;
+            (void)push_xform(Mat4::identity(), xi);
+            const int32_t off = (int32_t)chains.size();
+            for (int k = 0; k < f.chain_len; k++) chains.push_back(chains[f.chain_off + k]);
+            chains.push_back(xi);
+            const int32_t cid = next_chain_id++;
+            int32_t root = f.csg_root;
+            if (root < 0) {
+                root = (int32_t)csg_roots.size();
+                csg_roots.push_back(DCsgRoot{(int32_t)prims.size(), 0, (int32_t)csg_nodes.size(), 0});
+            }
+            csg_begin[f.item] = (int32_t)prims.size();
+            stack.push_back({f.item, 0, 0, -1, -1, root, 2});
+            stack.push_back({it.children[1], off, f.chain_len + 1, -1, cid, root, 0});
+            stack.push_back({f.item, 0, 0, -1, -1, root, 1});
+            stack.push_back({it.children[0], off, f.chain_len + 1, -1, cid, root, 0});
+            continue;
+        }
         if (it.material >= (int32_t)materials.size()) {
             set_error("shape references material %d, only %zu defined", it.material, materials.size());
             return RTC_ERR_INVALID;
@@ -252,7 +296,7 @@ int Scene::flatten() {
             chains.push_back(xi);
             const int32_t cid = next_chain_id++;
             for (auto c = it.children.rbegin(); c != it.children.rend(); ++c)
-                stack.push_back({*c, off, f.chain_len + 1, it.material, cid});
+                stack.push_back({*c, off, f.chain_len + 1, it.material, cid, f.csg_root, 0});
         } else if (it.kind == Item::SHAPE) {
             if (it.material < 0) {
                 set_error("shape without a material");
@@ -295,6 +339,7 @@ int Scene::flatten() {
             if (bounded) world_bounds(lb, p.chain_off, p.chain_len, wb);
             prims.push_back(p);
             prim_anc_id.push_back(f.chain_len > 0 ? f.chain_id : -1);
+            prim_csg.push_back(f.csg_root);
             prim_bounds.push_back(wb);
             prim_bounded.push_back(bounded ? 1 : 0);
         } else {
@@ -343,6 +388,7 @@ int Scene::flatten() {
                 for (int a = 0; a < 3; a++) finite = finite && std::isfinite(wb.lo[a]) && std::isfinite(wb.hi[a]);
                 prims.push_back(p);
                 prim_anc_id.push_back(f.chain_len > 0 ? f.chain_id : -1);
+                prim_csg.push_back(f.csg_root);
                 prim_bounds.push_back(wb);
                 prim_bounded.push_back(finite ? 1 : 0);
             }
@@ -356,8 +402,34 @@ int Scene::flatten() {
         if (ok)
             for (int a = 0; a < 3; a++) ok = ok && std::isfinite(prim_bounds[i].lo[a]) && std::isfinite(prim_bounds[i].hi[a]);
         prim_bounded[i] = ok;
-        if (!ok) unbounded.push_back((int32_t)i);
     }
+    // one pseudo-primitive per Csg tree, after the real primitives (whose indices -- identity, tie order -- stay what
+    // the depth-first walk gave them): the union of the leaves' boxes bounds whatever the operations keep
+    const size_t n_real = prims.size();
+    for (size_t r = 0; r < csg_roots.size(); r++) {
+        const DCsgRoot &root = csg_roots[r];
+        DPrim p{};
+        p.type = PT_CSG;
+        p.tri = (int32_t)r;
+        p.own_xform = -1;
+        p.minimum = -INF, p.maximum = INF;
+        Bounds wb;
+        bounds_empty(wb);
+        bool ok = root.n_prims > 0;
+        for (int32_t k = 0; k < root.n_prims; k++) {
+            const size_t q = (size_t)root.prim_first + k;
+            ok = ok && prim_bounded[q];
+            for (int a = 0; a < 3; a++)
+                wb.lo[a] = std::min(wb.lo[a], prim_bounds[q].lo[a]), wb.hi[a] = std::max(wb.hi[a], prim_bounds[q].hi[a]);
+        }
+        prims.push_back(p);
+        prim_anc_id.push_back(-1);
+        prim_csg.push_back(-1);
+        prim_bounds.push_back(wb);
+        prim_bounded.push_back(ok ? 1 : 0);
+    }
+    for (size_t i = 0; i < prims.size(); i++)
+        if (!prim_bounded[i] && (i >= n_real || prim_csg[i] < 0)) unbounded.push_back((int32_t)i);
     return RTC_OK;
 }
 
@@ -530,7 +602,7 @@ void Scene::build_bvh() {
     for (int k = 0; k < 3; k++) root_min[k] = root_max[k] = 0.0;
     std::vector<int32_t> order;
     for (size_t i = 0; i < prims.size(); i++)
-        if (prim_bounded[i]) order.push_back((int32_t)i);
+        if (prim_bounded[i] && prim_csg[i] < 0) order.push_back((int32_t)i);  // (leaves of a Csg: through its tree only)
     if (order.empty()) return;
 
     constexpr uint32_t DEPTH_LIMIT = 30;  // device traversal stack holds 32 entries (the kernel flags an overflow)
@@ -789,6 +861,13 @@ int Scene::upload(int dev, DeviceReplica &rep) {
             const DPrim &p = prims[pi];
             DLeaf l{};
             l.type = (uint8_t)p.type, l.prim = pi, l.closed = (uint8_t)p.closed;
+            if (prim_csg[pi] >= 0) l.closed |= RTC_LEAF_IN_CSG;
+            if (p.type == PT_CSG) {
+                l.anc_off = p.tri;  // the tree
+                l.anc_id = -1;
+                l.minimum = l.maximum = 0;
+                return l;
+            }
             l.minimum = p.minimum, l.maximum = p.maximum;
             l.anc_off = p.chain_off;
             l.anc_id = prim_anc_id[pi];
@@ -830,6 +909,9 @@ int Scene::upload(int dev, DeviceReplica &rep) {
     dscene.n_bvh_nodes = (int32_t)((quantized_nodes && RTC_BVH4) ? bvh4.size() : bvh.size());
     dscene.n_lights = (int32_t)lights.size();
     dscene.n_materials = (int32_t)dmaterials.size();
+    if ((rc = upload_vec(rep, csg_roots, dscene.csg_roots))) return rc;
+    if ((rc = upload_vec(rep, csg_nodes, dscene.csg_nodes))) return rc;
+    dscene.any_csg = csg_roots.empty() ? 0 : 1;
     dscene.all_cast_shadow = 1;
     dscene.any_pattern = 0;
     dscene.any_group = 0;

@@ -14,7 +14,7 @@ void set_error(const char *fmt, ...);
 
 // One entry of the builder tree (mirrors the reference's Shape tree: shape.rs Group / leaf shapes).
 struct Item {
-    enum Kind { GROUP, SHAPE, TRIANGLES } kind;
+    enum Kind { GROUP, SHAPE, TRIANGLES, CSG } kind;  // CSG: `type` holds the rtc_csg_op, children = {left, right}
     int parent = -1;  // item index of the enclosing group or -1 (member of World.objects)
     Mat4 transform = Mat4::identity();
     int32_t material = -1;
@@ -94,6 +94,10 @@ struct Scene {
     std::vector<Bounds> prim_bounds;  // world-space, padded; only meaningful for bounded prims
     std::vector<uint8_t> prim_bounded;
     std::vector<int32_t> prim_anc_id;  // ancestor-chain identity per primitive (-1: top level)
+    std::vector<int32_t> prim_csg;     // Csg tree a primitive is a leaf of (-1: none); such primitives are reached only
+                                       // through the tree's pseudo-primitive (PT_CSG, appended after the real ones)
+    std::vector<DCsgRoot> csg_roots;
+    std::vector<DCsgNode> csg_nodes;
     uint32_t bvh_max_depth = 0, bvh_max_leaf = 0;
     uint32_t n_transparent_prims = 0;
     int32_t root_ref = 0;

@@ -22,8 +22,26 @@ enum PrimType : int32_t {
     PT_CYLINDER = 3,
     PT_CONE = 4,
     PT_TRIANGLE = 5,
-    PT_SMOOTH_TRIANGLE = 6
+    PT_SMOOTH_TRIANGLE = 6,
+    PT_CSG = 7  // pseudo-primitive: one whole Csg tree (shape.rs:2146-2291) as the traversal sees it
 };
+
+// Csg (shape.rs:2146-2291).  A Csg tree is one entry of the intersection structures (always-tested list or BVH leaf):
+// filter_intersections needs the records of its leaves in sorted order, which the streaming fold of the rest of the
+// path does not keep, so the kernel collects them into a small per-lane array, sorts, runs the filters of the tree's
+// Csg nodes bottom-up and feeds what survives to the fold.  The leaves of a tree are consecutive primitives (depth-
+// first order); their DLeaf records carry RTC_LEAF_IN_CSG so that the lists skip them.
+struct DCsgRoot {
+    int32_t prim_first, n_prims;  // the tree's leaf primitives
+    int32_t node_first, n_nodes;  // its Csg nodes in post-order (children before parents; the last one is the root)
+};
+struct DCsgNode {
+    int32_t op;                 // rtc_csg_op
+    int32_t l_first, l_count;   // leaves of the left / right operand, relative to DCsgRoot::prim_first
+    int32_t r_first, r_count;
+};
+#define RTC_LEAF_IN_CSG 2    // bit of DLeaf::closed
+#define RTC_CSG_MAX_RECORDS 32  // records one ray may collect from one Csg tree (more: overflow flag)
 
 struct DXform {
     double inv[12];  // inverse(T) rows 0..2, row-major 3x4
@@ -185,6 +203,11 @@ struct DScene {
     // otherwise pay for with v_readlane reloads of other arguments) and only its two sizes travel by value.
     const DCamera *cam;
     uint32_t hsize, vsize;
+    // ---- rarely used (kept last so that the blocks above keep their places in the argument registers) ----
+    const DCsgRoot *csg_roots;
+    const DCsgNode *csg_nodes;
+    int32_t any_csg;
+    int32_t pad1;
 };
 
 // Work buffer of the persistent schedule (one per scene, device memory; the first RTC_WORK_RESET_BYTES are zeroed

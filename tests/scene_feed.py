@@ -50,6 +50,10 @@ def _add(w, obj, parent, mcache, pcache):
                     parent=parent)
         for c in obj.children:
             _add(w, c, g, mcache, pcache)
+    elif isinstance(obj, rtc.Csg):
+        c = w.csg(obj.operation, parent=parent)
+        _add(w, obj.left, c, mcache, pcache)
+        _add(w, obj.right, c, mcache, pcache)
     elif isinstance(obj, rtc.Shape):
         w.shape(obj.kind, transform=obj.transformation.m, material=_material(w, obj.material, mcache, pcache),
                 parent=parent, minimum=obj.minimum, maximum=obj.maximum, closed=obj.closed)

@@ -281,3 +281,57 @@ def test_shadow_rays_behind_the_surface_are_counted_not_traced():
     # one light: the reference traces one shadow ray per shaded hit and per re-traced subtree; the GPU traces each
     # subtree once (Q3), so with a single light the two counts coincide
     assert st["shadow_rays"] + st["shadow_rays_skipped"] == ow.last_stats["shadow"]
+
+
+def _csg_scene():
+    G = rtc
+    red = G.Material(color=(1, 0.3, 0.2), reflectivity=0.2)
+    blue = G.Material(color=(0.2, 0.4, 1), specular=0.4)
+    glass = G.Material(color=(0.9, 1, 0.9), transparency=0.85, reflectivity=0.5, refractive_index=1.5, diffuse=0.15)
+    # difference: a cube with a spherical bite taken out (shape.rs:2195)
+    bite = G.CsgDifference(G.Cube(M.scaling(0.8, 0.8, 0.8).rotate_y(0.5).translate(-2.4, 0.8, 0), red),
+                           G.Sphere(M.translation(-2.0, 1.5, -0.6), blue))
+    # intersection: the lens two spheres share (shape.rs:2194), in glass (containers see both leaves)
+    lens = G.CsgIntersection(G.Sphere(M.translation(-0.45, 1, -1), glass), G.Sphere(M.translation(0.45, 1, -1), glass))
+    # union of a capped cylinder and a cone, inside a transformed group (shape.rs:2193; chain of group + Csg levels)
+    grp = G.Group(transformation=M.rotation_z(0.25).translate(2.3, 0, 0.5))
+    grp.add_child(G.CsgUnion(G.Cylinder(M.scaling(0.5, 1, 0.5), red, 0.0, 1.2, True),
+                             G.Cone(M.scaling(0.8, 0.8, 0.8).translate(0, 2.0, 0), blue, -1.0, 0.0, True)))
+    # nested: (cube - sphere) intersected with a group of two spheres
+    inner = G.CsgDifference(G.Cube(M.scaling(0.6, 0.6, 0.6), blue), G.Sphere(M.scaling(0.75, 0.75, 0.75), red))
+    pair = G.Group(children=[G.Sphere(M.translation(0.3, 0.2, 0), red), G.Sphere(M.translation(-0.3, -0.2, 0), blue)])
+    nested = G.Group(transformation=M.rotation_y(0.6).rotate_x(-0.4).translate(0.2, 0.7, -3.2), children=[G.CsgIntersection(inner, pair)])
+    objs = [_floor(color=(0.85, 0.85, 0.8), reflectivity=0.15), bite, lens, grp, nested]
+    return rtc.World(objs, LIGHT), _cam(144, 88, (0, 3, -8), (0, 1, 0))
+
+
+def test_csg_union_intersection_difference_nested():
+    # shape.rs:2146-2291 through the C ABI: rtc_scene_begin_csg / end_csg
+    world, cam = _csg_scene()
+    img = _check(world, cam, "csg")
+    scene = cam.compile(world, device=0)
+    try:
+        a = scene.render(use_bvh=1, schedule=1)
+        b = scene.render(use_bvh=2, schedule=1)  # the tree as an entry of the brute-force list
+        c = scene.render(depth=2, use_bvh=1)
+        d = scene.render(depth=2, use_bvh=2)
+    finally:
+        scene.close()
+    assert np.array_equal(a, b) and np.array_equal(a, img)
+    assert np.array_equal(c, d)
+
+
+def test_many_csg_objects_go_through_the_bvh():
+    # a grid of small Csg objects: enough bounded entries for the BVH, each tree one leaf of it
+    G = rtc
+    objs = [_floor(color=(0.9, 0.9, 0.9), reflectivity=0.1)]
+    k = 0
+    for i in range(-3, 4):
+        for j in range(3):
+            t = M.scaling(0.35, 0.35, 0.35).translate(i * 0.9, 0.35, j * 1.1 - 1.0)
+            t2 = M.scaling(0.25, 0.25, 0.25).translate(i * 0.9 + 0.15, 0.55, j * 1.1 - 1.15)
+            mat = G.Material(color=(0.3 + 0.1 * (k % 7), 0.8 - 0.1 * (k % 5), 0.5), reflectivity=0.2 * (k % 2))
+            op = (G.CsgUnion, G.CsgIntersection, G.CsgDifference)[k % 3]
+            objs.append(op(G.Cube(t, mat), G.Sphere(t2, mat)))
+            k += 1
+    _check(rtc.World(objs, LIGHT), _cam(128, 80, (0, 3.5, -7), (0, 0.3, 0)), "csg grid")

@@ -1,5 +1,6 @@
 """Host side of the boundary without a GPU: flattening, BVH, tiling, error behaviour (rtc_scene_commit with
 device = -1 does the host work only)."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -120,3 +121,37 @@ def test_host_matrix_known_answers():
     t = rtc.Matrix.identity().rotate_x(math.pi / 2).scale(5, 5, 5).translate(10, 5, 7)
     p = t.m @ np.array([1.0, 0.0, 1.0, 1.0])
     assert np.all(np.abs(p[:3] - np.array([15.0, 0.0, 7.0])) < 1e-5)
+
+
+def test_csg_call_order_and_flattening():
+    # Csg::new takes exactly a left and a right shape (shape.rs:2166); the flattener turns the tree into one entry
+    # of the intersection structures
+    N = rtc._native
+    L = N.lib()
+    h = C.c_void_p(L.rtc_scene_create())
+    m = N.Material()
+    L.rtc_material_default(C.byref(m))
+    mid = C.c_uint32()
+    assert L.rtc_scene_add_material(h, C.byref(m), C.byref(mid)) == N.OK
+    assert L.rtc_scene_begin_csg(h, 7) == N.ERR_INVALID
+    assert L.rtc_scene_begin_csg(h, N.CSG_DIFFERENCE) == N.OK
+    assert L.rtc_scene_end_csg(h) == N.ERR_STATE                      # no operands yet
+    assert L.rtc_scene_add_shape(h, N.CUBE, None, mid.value, 0.0, 0.0, 0) == N.OK
+    pts = (C.c_double * 9)(0, 0, 0, 1, 0, 0, 0, 1, 0)
+    assert L.rtc_scene_add_triangles(h, 1, pts, None, mid.value) == N.ERR_INVALID   # shape.rs:1521-1523
+    assert L.rtc_scene_end_group(h) == N.ERR_STATE                    # the open node is a Csg
+    assert L.rtc_scene_begin_csg(h, N.CSG_UNION) == N.OK              # right operand: another Csg
+    assert L.rtc_scene_add_shape(h, N.SPHERE, None, mid.value, 0.0, 0.0, 0) == N.OK
+    assert L.rtc_scene_add_shape(h, N.SPHERE, None, mid.value, 0.0, 0.0, 0) == N.OK
+    assert L.rtc_scene_add_shape(h, N.SPHERE, None, mid.value, 0.0, 0.0, 0) == N.ERR_STATE  # a third operand
+    assert L.rtc_scene_end_csg(h) == N.OK
+    assert L.rtc_scene_add_shape(h, N.SPHERE, None, mid.value, 0.0, 0.0, 0) == N.ERR_STATE
+    assert L.rtc_scene_end_csg(h) == N.OK
+    assert L.rtc_scene_set_camera(h, 16, 16, 1.0, None) == N.OK
+    assert L.rtc_scene_commit(h, -1) == N.OK
+    info = N.SceneInfo()
+    assert L.rtc_scene_get_info(h, C.byref(info)) == N.OK
+    assert info.n_prims == 3 + 1          # three leaves + the tree's pseudo-primitive
+    it = N.ItemInfo()
+    assert L.rtc_scene_get_item(h, 0, C.byref(it)) == N.OK and it.kind == 3 and it.shape_type == N.CSG_DIFFERENCE
+    L.rtc_scene_destroy(h)
