@@ -625,7 +625,8 @@ DEV double safe_rcp(double d) {
 #define RTC_PREFETCH 0
 #endif
 #ifndef RTC_BRANCHFREE
-#define RTC_BRANCHFREE 1  // the traversal's exchange with its stack as selects around LDS accesses (0: branches, round 1)
+#define RTC_BRANCHFREE 1  // large hierarchies (incoherent rays): the traversal's exchange with its stack as selects
+                          // around LDS accesses instead of branches (stress 4K -4 %; coherent small scenes +3 %: not there)
 #endif
 // first line of the record a child reference of a quantised binary node points at: another node, or the first
 // primitive record of a leaf run
@@ -1413,20 +1414,17 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         // sphere with a diagonal + translation inverse: 64-byte record, the off-diagonal zeros are
                         // rebuilt with their signs and the arithmetic is the general sphere's (same bits)
                         const DLeafS &L = s.leaves_s[(pos++) & (RTC_LEAF_COMPACT - 1)];
-                        double a[12];
-                        const unsigned long long zs = L.zsign;
-                        a[0] = L.d[0], a[5] = L.d[1], a[10] = L.d[2];
-                        a[3] = L.t[0], a[7] = L.t[1], a[11] = L.t[2];
-                        a[1] = __longlong_as_double((long long)((zs & 1ull) << 63));
-                        a[2] = __longlong_as_double((long long)(((zs >> 1) & 1ull) << 63));
-                        a[4] = __longlong_as_double((long long)(((zs >> 2) & 1ull) << 63));
-                        a[6] = __longlong_as_double((long long)(((zs >> 3) & 1ull) << 63));
-                        a[8] = __longlong_as_double((long long)(((zs >> 4) & 1ull) << 63));
-                        a[9] = __longlong_as_double((long long)(((zs >> 5) & 1ull) << 63));
                         CNT(ST_XFORM, 1);
                         CNT(ST_PRIM0 + PT_SPHERE, 1);
+                        // Ray::transform by a matrix whose off-diagonal entries are (signed) zeros.  The reference's
+                        // ((m00 x + m01 y) + m02 z) + m03 (matrix.rs:339-343) adds +-0 * y and +-0 * z to m00 x: for
+                        // finite y, z that changes nothing but, when m00 x is itself a zero, the SIGN of that zero --
+                        // and a zero's sign can reach no comparison of the sphere test (squares, sums with non-zero
+                        // terms, t > 0, t < limit).  So the two products per component are all that is computed
+                        // (r1 rebuilt the zeros with their signs: 33 more f64 instructions per test).
                         Ray q;
-                        q.o = xf_point((const double *)a, ray.o), q.d = xf_vector((const double *)a, ray.d);
+                        q.o = mk(L.d[0] * ray.o.x + L.t[0], L.d[1] * ray.o.y + L.t[1], L.d[2] * ray.o.z + L.t[2]);
+                        q.d = mk(L.d[0] * ray.d.x, L.d[1] * ray.d.y, L.d[2] * ray.d.z);
                         isect_sphere(q, T, L.prim);
                         end_prim(T, L.prim);
                         if (any_hit && T.prim >= 0) in_pass = false;
@@ -1470,7 +1468,11 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
 #if RTC_BRANCHFREE
                     // (the usual case -- every entry concerned sits in the LDS part of the stack -- is served without
                     // a branch: the top of the stack is read whether or not it will be popped, selects do the rest)
-                    if (sb <= RTC_LDS_STACK) {
+                    // (whether some lane's stack has grown out of its LDS part is asked once per step for the whole wave:
+                    // a scalar branch instead of exec-mask bookkeeping around the rare case; a step moves a stack by at
+                    // most RTC_NODES_PER_STEP entries)
+                    const bool shallow = QNODES && __ballot(sb + RTC_NODES_PER_STEP >= RTC_LDS_STACK) == 0ull;
+                    if (shallow) {
                         const int top = stack[(sb - 1) * RTC_WAVE];
                         const bool pop = ref == RTC_NO_NODE;
                         ref = pop ? top : ref;
@@ -1565,7 +1567,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         const bool left_first = tl <= tr;
                         const bool take_left = hl && (!hr || left_first);
 #if RTC_BRANCHFREE
-                        if (sb < RTC_LDS_STACK) {
+                        if (shallow) {
                             // the far child is stored above the top in any case (harmless when it is not pushed) and the
                             // entry below it read in any case (used when both boxes are missed): two LDS operations and
                             // five selects instead of three branches
@@ -1584,7 +1586,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                             RTC_POP(ref);
                     }
 #if RTC_BRANCHFREE
-                    {
+                    if (QNODES) {
                         // what the descent arrived at: another internal node (carried to the next step), the stack's
                         // bottom entry (every subtree has been dealt with) or a leaf's run of primitive records
                         const bool done = ref == RTC_NO_NODE, leaf = ref < 0 && !done;
@@ -1593,8 +1595,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         end = leaf ? (code >> 3) + (code & 7) + 1 : end;
                         cur = ref >= 0 ? ref : RTC_NO_NODE;
                         in_pass = !done;
-                    }
-#else
+                    } else
+#endif
                     if (ref >= 0) {
                         cur = ref;  // still an internal node: carry on at the next step
                     } else if (ref == RTC_NO_NODE) {
@@ -1606,7 +1608,6 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         end = pos + (code & 7) + 1;
                         cur = RTC_NO_NODE;
                     }
-#endif
                 }
 #undef RTC_PUSH
 #undef RTC_POP
@@ -1731,9 +1732,40 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         // for the mirror / glass spheres of the stress scene about half of all shadow passes).
         bool have_result = T.mode == MODE_SHADOW, need_setup = begin_lights, behind = false;
         if (begin_lights) li = 0, su = sv = 0, unshadowed = 0;
-        while (have_result || need_setup) {
-            if (have_result) {
-                have_result = false;
+        // (the set-up comes first in program order: a lane whose light is behind the surface falls through into the SAME
+        // execution of the lighting block that serves the lanes arriving with a shadow pass's result)
+#pragma clang loop unroll(disable)
+        for (;;) {
+            if (need_setup) {
+                need_setup = false;
+                const DLight &lt = s.lights[li];
+                const int lt_area = lt.is_area;
+                V3 lp = ld3(lt.position);
+                const V3 lt_pos = lp;
+                if (lt_area)  // AreaLight::point_on_light, light.rs:106-108
+                    lp = ld3(lt.corner) + ld3(lt.uvec) * ((double)su + 0.5) + ld3(lt.vvec) * ((double)sv + 0.5);
+                const V3 h_normal = unpark3(pk, PK_NORMAL);
+                const V3 over = unpark3(pk, PK_POINT) + h_normal * RTC_EPS;
+                const V3 dv = lp - over;  // world.rs:79-83
+                ray.o = over;
+                ray.d = normalize(dv);
+                T.lim = magnitude(dv);
+                T.prim = -1;
+                T.mode = MODE_SHADOW;
+#ifndef RTC_NO_SHADOW_SKIP
+                // Material::lighting's light vector (material.rs:39): towards light.position(), which for a point
+                // light is the direction just formed
+                const V3 lightv = lt_area ? normalize(lt_pos - over) : ray.d;
+                if (dot(lightv, h_normal) < 0.) {
+                    behind = true, have_result = true;
+                    CNT(ST_SHADOW_SKIPPED, lt_area ? lt.samples : 1u);
+                } else
+#endif
+                    CNT(ST_SHADOW, 1);
+            }
+            if (!have_result) break;  // a shadow pass starts (or the lane has nothing to do with lights this round)
+            have_result = false;
+            {
                 // World::is_shadowed (world.rs:78-91): only the NEAREST positive hit is consulted (Q5); when every
                 // material casts shadows that equals "some hit has 0 < t < distance" (any-hit early exit).
                 const bool shadowed = !behind && T.prim >= 0 &&
@@ -1778,34 +1810,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     need_setup = true;
                 else
                     finish = true, f_refl = m.reflectivity;
-            } else {
-                need_setup = false;
-                const DLight &lt = s.lights[li];
-                const int lt_area = lt.is_area;
-                V3 lp = ld3(lt.position);
-                const V3 lt_pos = lp;
-                if (lt_area)  // AreaLight::point_on_light, light.rs:106-108
-                    lp = ld3(lt.corner) + ld3(lt.uvec) * ((double)su + 0.5) + ld3(lt.vvec) * ((double)sv + 0.5);
-                const V3 h_normal = unpark3(pk, PK_NORMAL);
-                const V3 over = unpark3(pk, PK_POINT) + h_normal * RTC_EPS;
-                const V3 dv = lp - over;  // world.rs:79-83
-                ray.o = over;
-                ray.d = normalize(dv);
-                T.lim = magnitude(dv);
-                T.prim = -1;
-                T.mode = MODE_SHADOW;
-#ifndef RTC_NO_SHADOW_SKIP
-                // Material::lighting's light vector (material.rs:39): towards light.position(), which for a point
-                // light is the direction just formed
-                const V3 lightv = lt_area ? normalize(lt_pos - over) : ray.d;
-                if (dot(lightv, h_normal) < 0.) {
-                    behind = true, have_result = true;
-                    CNT(ST_SHADOW_SKIPPED, lt_area ? lt.samples : 1u);
-                    continue;
-                }
-#endif
-                CNT(ST_SHADOW, 1);
             }
+            if (!need_setup) break;
         }
         SUB_END(ST_SHADOW);
         if (finish) {
