@@ -217,13 +217,14 @@ int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_r
  * scene's launches: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO
  * counterpart in the reference.  Same arguments, same pixels.  The kernel's work buffer (tile counters, overflow flag,
  * mailboxes of the end-of-frame ray exchange) is a file-scope `static __device__` array of the library's code object
- * instead of the per-scene buffer that rtc_scene_commit allocated: RTC_STATIC_SCRATCH_BYTES per GPU, held until the
- * process ends.  Limits: collect_stats is refused; a persistent launch whose grid would exceed
- * RTC_STATIC_SCRATCH_WAVES resident waves is refused with RTC_ERR_INVALID (rtc_render_device switches the ray exchange
- * off instead).  Every scene on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
- * threads) race -- serialise them.  The call itself makes no hipMalloc / hipFree / allocating runtime call. */
+ * instead of the per-scene buffer that rtc_scene_commit allocated: RTC_STATIC_SCRATCH_BYTES (155 MB: per wave of the
+ * persistent grid a mailbox and, per lane, the ring of waiting refracted rays, for RTC_STATIC_SCRATCH_WAVES waves) per
+ * GPU, held until the process ends.  Limits: collect_stats is refused; frames beyond 2^26 8x8 tiles are refused (as by
+ * every entry point); the persistent grid is capped at RTC_STATIC_SCRATCH_WAVES resident waves (MI355X: 3072).  Every
+ * scene on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race -- serialise
+ * them.  The call itself makes no hipMalloc / hipFree / allocating runtime call. */
 #define RTC_STATIC_SCRATCH_WAVES 4096u
-#define RTC_STATIC_SCRATCH_BYTES (36864u + RTC_STATIC_SCRATCH_WAVES * 64u * 80u)
+#define RTC_STATIC_SCRATCH_BYTES (36864u + RTC_STATIC_SCRATCH_WAVES * 64u * (80u + 512u))
 int rtc_render_device_static(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream);
 /* Number of canvas rows owned by (tile_index, tile_count, tile_rows) and their canvas row numbers. */
 uint32_t rtc_local_rows(uint32_t vsize, uint32_t tile_rows, uint32_t tile_index, uint32_t tile_count);

@@ -624,6 +624,9 @@ DEV double safe_rcp(double d) {
 #ifndef RTC_PREFETCH
 #define RTC_PREFETCH 0
 #endif
+#ifndef RTC_RING_PAD
+#define RTC_RING_PAD 0
+#endif
 #ifndef RTC_BRANCHFREE
 #define RTC_BRANCHFREE 1  // large hierarchies (incoherent rays): the traversal's exchange with its stack as selects
                           // around LDS accesses instead of branches (stress 4K -4 %; coherent small scenes +3 %: not there)
@@ -935,7 +938,16 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     int remaining = 0;
     // waiting refracted rays: a ring (first entry at pbase) so that the OLDEST one -- the root of the largest subtree
     // still to be traced -- can be handed to a free lane at the end of the frame (see "tail" below)
-    Pending pend[RTC_MAX_DEPTH_STACK];
+    Pending pend_private[RTC_MAX_DEPTH_STACK];
+    // (persistent grid: the ring lives in the work buffer, one 64-byte line per entry, [wave][lane][entry])
+    Pending *const pend_global =
+        (Pending *)((char *)work + RTC_WORK_RING_OFFSET) + ((size_t)blockIdx.x * RTC_WAVE + threadIdx.x) * RTC_RING_SLOTS;
+#define pend_at(i) (*((PERSISTENT && RTC_RING_GLOBAL) ? &pend_global[i] : &pend_private[i]))
+#if RTC_RING_PAD
+    // A/B only ("the ring's write traffic"): every push also stores a second, unused entry, i.e.
+    // the ring's store traffic doubles while nothing else changes
+    Pending pend_pad[RTC_MAX_DEPTH_STACK];
+#endif
     double pend_mult[STATS ? RTC_MAX_DEPTH_STACK : 1];  // STATS only: `mult` of the waiting rays
     int sp = 0, pbase = 0;
     bool shared = false;  // this lane's pixel is being traced by more than one lane: results are ADDED to the canvas
@@ -1164,7 +1176,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     q.o = q.d = mk(0., 0., 0.), q.w = 0., q.remaining = 0;
                     double qm = 0.;
                     if ((int)lane == dl) {
-                        q = pend[pbase];
+                        q = pend_at(pbase);
                         if (STATS) qm = pend_mult[pbase];
                         pbase = (pbase + 1) & (RTC_MAX_DEPTH_STACK - 1);
                         sp--;
@@ -1210,7 +1222,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         if (alive && sp > 0) {
                             const unsigned rank = __builtin_amdgcn_mbcnt_hi(
                                 (unsigned)(don2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)don2, 0u));
-                            const Pending q = pend[pbase];
+                            const Pending q = pend_at(pbase);
                             const double qm = STATS ? pend_mult[pbase] : 0.;
                             pbase = (pbase + 1) & (RTC_MAX_DEPTH_STACK - 1);
                             sp--;
@@ -1707,11 +1719,18 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 if (!(sin2_t > 1.)) {
                     if (sp < RTC_MAX_DEPTH_STACK) {
                         const double cos_t = sqrt(1. - sin2_t);
-                        Pending &q = pend[RTC_PEND(sp)];
+                        Pending &q = pend_at(RTC_PEND(sp));
                         q.o = unpark3(pk, PK_POINT) - h_normal * RTC_EPS;  // under_point
                         q.d = h_normal * (n_ratio * cos_i - cos_t) - h_eye * n_ratio;
                         q.w = pk[PK_W * RTC_WAVE] * (nl * (m_transp * kt));
                         q.remaining = remaining;  // Q2: not decremented (world.rs:142)
+#if RTC_RING_PAD
+                        {
+                            Pending &z = pend_pad[RTC_PEND(sp)];
+                            z = q;
+                            asm volatile("" ::"v"(&z) : "memory");
+                        }
+#endif
                         if (STATS) pend_mult[RTC_PEND(sp)] = mult * nl;
                         sp++;
                     } else {
@@ -1843,7 +1862,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 alive = false;
             } else {
                 sp--;
-                const Pending q = pend[RTC_PEND(sp)];
+                const Pending q = pend_at(RTC_PEND(sp));
                 ray.o = q.o, ray.d = q.d, remaining = q.remaining;
                 pk[PK_W * RTC_WAVE] = q.w;
                 if (STATS) mult = pend_mult[RTC_PEND(sp)];
@@ -1892,6 +1911,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
 // counters, mailbox states) is cleared by launch_render's hipMemsetAsync before every persistent launch, and the
 // overflow flag is compared with a per-launch id, so stale values never match.
 static __device__ __align__(256) unsigned char scratch[RTC_WORK_TOTAL_BYTES];
+static_assert(sizeof(Pending) == 64 && RTC_MAX_DEPTH_STACK == RTC_RING_SLOTS, "one cache line per waiting ray");
 static_assert(RTC_WORK_TOTAL_BYTES == RTC_STATIC_SCRATCH_BYTES, "include/rtc.h states the size of the static scratch");
 static_assert(RTC_MAX_WAVES == RTC_STATIC_SCRATCH_WAVES, "include/rtc.h states the wave limit of the static scratch");
 static std::mutex g_scratch_mu;
@@ -1941,7 +1961,8 @@ static void launch_variant(const DScene &scene, DRenderParams &params, double *d
     if (params.persistent) {
         // occupancy is a property of the code object (queried once per variant); the CU count is this device's
         static const unsigned per_cu = resident_waves_per_cu(k_render<STATS, GROUPS, PATTERNS, true, QNODES>);
-        const unsigned cap = per_cu * n_cu;
+        // (the work buffer holds a mailbox and a ring of waiting rays per wave of the grid: RTC_MAX_WAVES of them)
+        const unsigned cap = (RTC_RING_GLOBAL && per_cu * n_cu > RTC_MAX_WAVES) ? RTC_MAX_WAVES : per_cu * n_cu;
         const unsigned waves = tiles < cap ? tiles : cap;
         static const unsigned refill_env = getenv("RTC_REFILL_MIN") ? (unsigned)atoi(getenv("RTC_REFILL_MIN")) : 0u;
         params.refill_min = refill_env ? refill_env : RTC_REFILL_MIN;

@@ -232,7 +232,15 @@ struct DScene {
 #define RTC_WORK_RESET_BYTES ((RTC_WORK_COUNTS + RTC_MAX_WAVES) * 4u)
 #define RTC_WORK_MBOX_BYTES RTC_WORK_RESET_BYTES
 #define RTC_MBOX_ITEM_U64 10u
-#define RTC_WORK_TOTAL_BYTES ((size_t)RTC_WORK_MBOX_BYTES + (size_t)RTC_MAX_WAVES * 64u * RTC_MBOX_ITEM_U64 * 8u)
+#define RTC_WORK_RING_OFFSET ((size_t)RTC_WORK_MBOX_BYTES + (size_t)RTC_MAX_WAVES * 64u * RTC_MBOX_ITEM_U64 * 8u)
+//   byte RTC_WORK_RING_OFFSET on (RTC_RING_GLOBAL): per wave and lane the ring of waiting refracted rays, RTC_RING_SLOTS
+//   entries of 64 bytes -- one cache line per entry, so that a push is one whole-line write and a pop one line read (as
+//   a private array the ring lives in swizzled scratch memory: 15 dwords of an entry in 15 different 256-byte rows)
+#ifndef RTC_RING_GLOBAL
+#define RTC_RING_GLOBAL 1
+#endif
+#define RTC_RING_SLOTS 8u
+#define RTC_WORK_TOTAL_BYTES (RTC_WORK_RING_OFFSET + (RTC_RING_GLOBAL ? (size_t)RTC_MAX_WAVES * 64u * RTC_RING_SLOTS * 64u : 0u))
 enum { RTC_MB_IDLE = 0, RTC_MB_HUNGRY = 1, RTC_MB_FILLING = 2, RTC_MB_FULL = 3, RTC_MB_CLOSED = 4 };
 
 struct DRenderParams {
