@@ -910,6 +910,13 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     int *const stack = &bvh_stack[lane];  // [entry][lane]: conflict free
     lds_f64 *const pk = (lds_f64 *)parked + lane;
     int deep_stack[RTC_BVH_STACK - RTC_LDS_STACK];  // scratch memory: entries beyond the LDS part (rare)
+#ifdef RTC_POP_PROBE
+    // measurement only (build with -DRTC_BRANCHFREE=0, read with collect_stats): entry distance of every waiting subtree,
+    // to count the stack entries that are popped after the ray's limit has moved in front of them.  The counters of the
+    // cube / cylinder tests carry the result (the probe is meant for scenes without those).
+    float probe_t[RTC_BVH_STACK];
+    float probe_push = 0.f;
+#endif
     const bool use_bvh = prm.use_bvh != 0;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     const unsigned n_tiles = prm.tiles_x * prm.tiles_y;
@@ -1386,8 +1393,23 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 if ((unsigned)__popcll(idle) >= prm.stay_min) break;
             }
             if (alive && in_pass) {
+#ifdef RTC_POP_PROBE
+#define RTC_PROBE_PUSH() do { if (sb < RTC_BVH_STACK) probe_t[sb] = probe_push; } while (0)
+#define RTC_PROBE_POP(v)                                                                                 \
+    do {                                                                                                 \
+        if (STATS && (v) != RTC_NO_NODE && sb < RTC_BVH_STACK) {                                         \
+            cnt.c[ST_PRIM0 + 2] += 1;                                                                    \
+            if (probe_t[sb] > f32_above(T.lim)) cnt.c[ST_PRIM0 + 3] += 1;                                \
+            if (probe_t[sb] > f32_above(T.lim) && (v) < 0) cnt.c[ST_PRIM0 + 4] += 1 + ((~(v)) & 7);      \
+        }                                                                                                \
+    } while (0)
+#else
+#define RTC_PROBE_PUSH() do { } while (0)
+#define RTC_PROBE_POP(v) do { } while (0)
+#endif
 #define RTC_PUSH(v)                                                 \
     do {                                                            \
+        RTC_PROBE_PUSH();                                           \
         if (sb < RTC_LDS_STACK)                                     \
             stack[sb * RTC_WAVE] = (v);                             \
         else if (sb < RTC_BVH_STACK)                                \
@@ -1401,6 +1423,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         sb--;                                                                                        \
         (v) = stack[(sb < RTC_LDS_STACK ? sb : RTC_LDS_STACK - 1) * RTC_WAVE];                       \
         if (sb >= RTC_LDS_STACK) (v) = deep_stack[(sb < RTC_BVH_STACK ? sb : RTC_BVH_STACK - 1) - RTC_LDS_STACK]; \
+        RTC_PROBE_POP(v);                                                                            \
     } while (0)
                 const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
                 const double lo = (T.mode == MODE_CONTAINER) ? -inf : 0.;
@@ -1590,6 +1613,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                             sb += both ? 1 : (any ? 0 : -1);
                             continue;
                         }
+#endif
+#ifdef RTC_POP_PROBE
+                        probe_push = left_first ? tr : tl;
 #endif
                         if (hl && hr) RTC_PUSH(left_first ? cr : cl);
                         if (hl || hr)
