@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 oi = mk(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z);
                 // slab plane of cell index q along axis a: t = (org + q * cell - o) / d = q * (cell / d) + (org / d + oi)
                 // (f32 nodes: the planes themselves, t = plane * inv_d + oi, |plane| <= the root box's largest coordinate)
-                if (QNODES) {
+                if (QNODES && !RTC_QF32) {
                     slab_axis(s.q_cell[0] * inv_d.x, fma(s.q_org[0], inv_d.x, oi.x), 65535., slab_ray.ax, slab_ray.bx);
                     slab_axis(s.q_cell[1] * inv_d.y, fma(s.q_org[1], inv_d.y, oi.y), 65535., slab_ray.ay, slab_ray.by);
                     slab_axis(s.q_cell[2] * inv_d.z, fma(s.q_org[2], inv_d.z, oi.z), 65535., slab_ray.az, slab_ray.bz);
@@ -1561,7 +1561,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         CNT(ST_BOX, 2);
                         bool hl, hr;
                         int cl, cr;
-                        if (QNODES) {
+                        if (QNODES && !RTC_QF32) {
                             const uint4 *np = (const uint4 *)(s.bvh_q + ref);
 #if RTC_LDS_TOP
                             uint4 w0, w1;

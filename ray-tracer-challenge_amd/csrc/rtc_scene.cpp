@@ -841,7 +841,9 @@ int Scene::upload(int dev, DeviceReplica &rep) {
     if ((rc = upload_vec(rep, dmaterials, dscene.materials))) return rc;
     if ((rc = upload_vec(rep, lights, dscene.lights))) return rc;
     if ((rc = upload_vec(rep, dpatterns, dscene.patterns))) return rc;
-    if (quantized_nodes) {
+    if (quantized_nodes && RTC_QF32) {
+        if ((rc = upload_vec(rep, bvh, dscene.bvh))) return rc;
+    } else if (quantized_nodes) {
         if (RTC_BVH4) {
             if ((rc = upload_vec(rep, bvh4, dscene.bvh4))) return rc;
         } else {

@@ -137,6 +137,9 @@ struct DPattern {
 // ~((first << 3) | (count - 1)) with `first` an offset into DScene::leaves (or RTC_LEAF_COMPACT | offset into
 // DScene::leaves_s).  The "paired" flags of the children
 // (see Scene::build_bvh) live in DScene::node_flags, read by the containers pass only.
+#ifndef RTC_QF32
+#define RTC_QF32 0  // A/B: large hierarchies keep 64-byte f32 nodes (no conversions in the box test, twice the node bytes)
+#endif
 struct DBvhNode {
     float lmin[3], lmax[3];
     float rmin[3], rmax[3];

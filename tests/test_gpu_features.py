@@ -335,3 +335,40 @@ def test_many_csg_objects_go_through_the_bvh():
             objs.append(op(G.Cube(t, mat), G.Sphere(t2, mat)))
             k += 1
     _check(rtc.World(objs, LIGHT), _cam(128, 80, (0, 3.5, -7), (0, 0.3, 0)), "csg grid")
+
+
+def test_edge_cases_empty_world_tiny_cameras_unbounded_only_and_depth_limit():
+    # the corners of the boundary: nothing to hit (world.rs:30-38 -> black), cameras one pixel wide / high (Q1: the
+    # last row and column are never rendered, camera.rs:72,78), a world of unbounded primitives only (no BVH at
+    # all), the deepest bounce budget the ring of waiting rays holds (8) and one beyond it (an error, not a canvas)
+    light = LIGHT
+    for objs, cam, label in (
+            ([], _cam(40, 24), "empty world"),
+            ([_floor(color=(0.3, 0.6, 0.9), reflectivity=0.5)], _cam(33, 17), "one plane, odd canvas"),
+            ([_floor(color=(1, 1, 1)), rtc.Plane(M.rotation_x(PI / 2).translate(0, 0, 6), rtc.Material(color=(0.8, 0.3, 0.3), reflectivity=0.9)),
+              rtc.Cylinder(M.scaling(0.5, 1, 0.5).translate(0, 0, 1), rtc.Material(transparency=0.8, refractive_index=1.3, reflectivity=0.4))],
+             _cam(48, 32), "unbounded primitives only"),
+            ([rtc.Sphere(M.translation(0, 1, 0))], _cam(1, 9), "one column"),
+            ([rtc.Sphere(M.translation(0, 1, 0))], _cam(9, 1), "one row"),
+            ([rtc.Sphere(M.translation(0, 1, 0))], _cam(2, 2), "one rendered pixel")):
+        scene = cam.compile(rtc.World(objs, light), device=0)
+        try:
+            for schedule in (1, 2):
+                gpu = scene.render(schedule=schedule)
+                ref = sf.to_oracle(rtc.World(objs, light), cam).render()
+                rep = sf.compare(gpu, ref)
+                print(f"[parity] {label} schedule {schedule}: {rep}")
+                assert rep["nan"] == 0 and rep["max_8bit"] <= 1 and rep["max_abs"] < 1e-9, (label, rep)
+                if not objs or min(cam.hsize, cam.vsize) == 1:
+                    assert np.all(gpu == 0.0), label
+        finally:
+            scene.close()
+    world, cam = _glass_scene(64, 40)
+    _check(world, cam, "depth 8", depth=8)
+    scene = cam.compile(world, device=0)
+    try:
+        with pytest.raises(rtc.RtcError):
+            scene.render(depth=9)
+        assert not np.isnan(scene.render(depth=0)).any()
+    finally:
+        scene.close()
