@@ -1559,6 +1559,9 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         }
                         float tl, tr;
                         CNT(ST_BOX, 2);
+#ifdef RTC_MODE_PROBE  // measurement only: box tests by pass kind in the cube / cylinder / cone counters
+                        CNT(ST_PRIM0 + 2 + T.mode, 2);
+#endif
                         bool hl, hr;
                         int cl, cr;
                         if (QNODES && !RTC_QF32) {
