@@ -6,6 +6,9 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <memory>
+#include <thread>
+#include <atomic>
 #include <limits>
 #include <vector>
 
@@ -520,8 +523,13 @@ int rtc_scene_last_stats(rtc_scene *scene, rtc_stats *stats) {
 // chunk k is copied out of its staging buffer.  place(offset, src, n) stores n bytes that start `offset` bytes into
 // the device buffer.
 typedef std::function<void(size_t, const char *, size_t)> Place;
+// Three staging buffers, and the copy out of them shared by a few host threads: with the DMA engine writing into host
+// memory at the same time ONE thread moves ~27 GB/s, which made the copy -- not PCIe -- the limit of a 4K frame's
+// download (tools/micro/d2h_pipeline.hip: 7.1 ms with one thread, 4.3 ms with two, DMA alone 3.5 ms).  The helpers live
+// for one call; place() is called on disjoint byte ranges.  RTC_COPY_THREADS overrides the count (1 = the caller only).
 static int staged_download(Scene &s, const char *d_src, size_t bytes, hipStream_t st, const Place &place) {
     const size_t CHUNK = (size_t)16 << 20;
+    constexpr size_t NBUF = sizeof(s.h_stage) / sizeof(s.h_stage[0]);
     if (!s.h_stage[0]) {
         for (void *&h : s.h_stage)
             if (hipHostMalloc(&h, CHUNK, hipHostMallocDefault) != hipSuccess) {
@@ -530,7 +538,7 @@ static int staged_download(Scene &s, const char *d_src, size_t bytes, hipStream_
             }
         s.stage_bytes = CHUNK;
     }
-    hipEvent_t ev[2];
+    hipEvent_t ev[NBUF];
     for (hipEvent_t &e : ev)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
             set_error("hipEventCreate failed");
@@ -538,27 +546,57 @@ static int staged_download(Scene &s, const char *d_src, size_t bytes, hipStream_
         }
     int rc = RTC_OK;
     const size_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
+    static const int threads_env = getenv("RTC_COPY_THREADS") ? atoi(getenv("RTC_COPY_THREADS")) : 0;
+    const int threads = n_chunks < 2 ? 1 : std::max(1, std::min(8, threads_env > 0 ? threads_env : 3));
+    auto chunk_len = [&](size_t k) { return std::min(CHUNK, bytes - k * CHUNK); };
+    // helper t copies slice t of every chunk once the caller's thread has seen the chunk arrive
+    std::atomic<size_t> ready{0};
+    std::atomic<bool> stop{false};
+    std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[std::max<size_t>(n_chunks, 1)]);
+    for (size_t k = 0; k < n_chunks; k++) done[k].store(0);
+    auto slice = [&](size_t k, int t) {
+        const size_t n = chunk_len(k), a = n * (size_t)t / (size_t)threads, b = n * (size_t)(t + 1) / (size_t)threads;
+        if (b > a) place(k * CHUNK + a, (const char *)s.h_stage[k % NBUF] + a, b - a);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++)
+        pool.emplace_back([&, t] {
+            for (size_t k = 0; k < n_chunks; k++) {
+                while (ready.load(std::memory_order_acquire) <= k) {
+                    if (stop.load(std::memory_order_relaxed)) return;
+                    std::this_thread::yield();
+                }
+                slice(k, t);
+                done[k].fetch_add(1, std::memory_order_release);
+            }
+        });
     auto issue = [&](size_t k) {
-        const size_t off = k * CHUNK, n = std::min(CHUNK, bytes - off);
-        if (hipMemcpyAsync(s.h_stage[k & 1], d_src + off, n, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipEventRecord(ev[k & 1], st) != hipSuccess) {
+        // (the buffer is free again: every thread is through with the chunk that used it last)
+        if (k >= NBUF)
+            while (done[k - NBUF].load(std::memory_order_acquire) < threads - 1) std::this_thread::yield();
+        if (hipMemcpyAsync(s.h_stage[k % NBUF], d_src + k * CHUNK, chunk_len(k), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipEventRecord(ev[k % NBUF], st) != hipSuccess) {
             set_error("device-to-host copy of the canvas failed: %s", hipGetErrorString(hipGetLastError()));
             rc = RTC_ERR_HIP;
         }
     };
-    if (n_chunks > 0) issue(0);
+    for (size_t k = 0; k + 1 < NBUF && k < n_chunks && rc == RTC_OK; k++) issue(k);
     for (size_t k = 0; k < n_chunks && rc == RTC_OK; k++) {
-        if (k + 1 < n_chunks) issue(k + 1);
+        if (k + NBUF - 1 < n_chunks) issue(k + NBUF - 1);
         if (rc != RTC_OK) break;
-        if (hipEventSynchronize(ev[k & 1]) != hipSuccess) {
+        if (hipEventSynchronize(ev[k % NBUF]) != hipSuccess) {
             set_error("device-to-host copy of the canvas failed: %s", hipGetErrorString(hipGetLastError()));
             rc = RTC_ERR_HIP;
             break;
         }
-        const size_t off = k * CHUNK;
-        place(off, (const char *)s.h_stage[k & 1], std::min(CHUNK, bytes - off));
+        ready.store(k + 1, std::memory_order_release);
+        slice(k, 0);
     }
-    if (rc != RTC_OK) (void)hipStreamSynchronize(st);  // nothing may still write the staging buffers
+    if (rc != RTC_OK) {
+        stop.store(true);
+        (void)hipStreamSynchronize(st);  // nothing may still write the staging buffers
+    }
+    for (std::thread &th : pool) th.join();
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     return rc;
 }

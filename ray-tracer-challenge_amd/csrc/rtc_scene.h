@@ -106,7 +106,7 @@ struct Scene {
     // ---- device state: reps[0] is the primary device (`device`), where a multi-device frame is assembled ----
     std::vector<DeviceReplica> reps;
     uint64_t device_bytes = 0;
-    void *h_stage[2] = {nullptr, nullptr};  // pinned staging buffers of rtc_render's device-to-host copy
+    void *h_stage[3] = {nullptr, nullptr, nullptr};  // pinned staging buffers of rtc_render's device-to-host copy
     size_t stage_bytes = 0;
     rtc_stats last_stats{};
     bool have_last_stats = false;
