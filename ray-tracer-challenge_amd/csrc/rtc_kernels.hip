@@ -1595,10 +1595,10 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                             cl = (int)w1.z, cr = (int)w1.w;
                         } else {
                             const DBvhNode &n = s.bvh[ref];
-                            hl = slab32((f32x2){n.lmin[0], n.lmax[0]}, (f32x2){n.lmin[1], n.lmax[1]},
-                                        (f32x2){n.lmin[2], n.lmax[2]}, slab_ray, (flags & 1u) ? lim_lo32 : lo32, hi32, tl);
-                            hr = slab32((f32x2){n.rmin[0], n.rmax[0]}, (f32x2){n.rmin[1], n.rmax[1]},
-                                        (f32x2){n.rmin[2], n.rmax[2]}, slab_ray, (flags & 2u) ? lim_lo32 : lo32, hi32, tr);
+                            hl = slab32((f32x2){n.lx[0], n.lx[1]}, (f32x2){n.ly[0], n.ly[1]}, (f32x2){n.lz[0], n.lz[1]},
+                                        slab_ray, (flags & 1u) ? lim_lo32 : lo32, hi32, tl);
+                            hr = slab32((f32x2){n.rx[0], n.rx[1]}, (f32x2){n.ry[0], n.ry[1]}, (f32x2){n.rz[0], n.rz[1]},
+                                        slab_ray, (flags & 2u) ? lim_lo32 : lo32, hi32, tr);
                             cl = n.left, cr = n.right;
                         }
                         // near child first, the far one waits on the stack (selects, not a branch per case)

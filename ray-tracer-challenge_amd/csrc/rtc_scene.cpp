@@ -708,8 +708,9 @@ void Scene::build_bvh() {
                 DBvhNode d{};
                 DBvhNodeQ q{};
                 for (int k = 0; k < 3; k++) {
-                    d.lmin[k] = f32_down(l.b.lo[k]), d.lmax[k] = f32_up(l.b.hi[k]);
-                    d.rmin[k] = f32_down(r.b.lo[k]), d.rmax[k] = f32_up(r.b.hi[k]);
+                    float *lp = k == 0 ? d.lx : k == 1 ? d.ly : d.lz, *rp = k == 0 ? d.rx : k == 1 ? d.ry : d.rz;
+                    lp[0] = f32_down(l.b.lo[k]), lp[1] = f32_up(l.b.hi[k]);
+                    rp[0] = f32_down(r.b.lo[k]), rp[1] = f32_up(r.b.hi[k]);
                     q.lmin[k] = q_down(l.b.lo[k], k), q.lmax[k] = q_up(l.b.hi[k], k);
                     q.rmin[k] = q_down(r.b.lo[k], k), q.rmax[k] = q_up(r.b.hi[k], k);
                 }

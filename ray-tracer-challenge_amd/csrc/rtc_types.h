@@ -141,8 +141,10 @@ struct DPattern {
 #define RTC_QF32 0  // A/B: large hierarchies keep 64-byte f32 nodes (no conversions in the box test, twice the node bytes)
 #endif
 struct DBvhNode {
-    float lmin[3], lmax[3];
-    float rmin[3], rmax[3];
+    // {min, max} per axis, left child then right child: each pair arrives in an even-aligned register pair, which is what
+    // the slab test's packed FMA takes (with min[3], max[3] the compiler spent ten moves per visit on pairing them up)
+    float lx[2], ly[2], lz[2];
+    float rx[2], ry[2], rz[2];
     int32_t left, right;
     int32_t pad[2];
 };
