@@ -88,10 +88,15 @@ typedef struct rtc_render_opts {
                             schedule 1's */
     uint32_t max_rays_per_pixel; /* guard against runaway ray trees (refraction keeps the bounce budget, world.rs:142):
                             a lane that traces more rays than this for one pixel gives up, the pixel becomes NaN and the
-                            call reports RTC_ERR_OVERFLOW.  0 = default (65536) */
+                            call reports RTC_ERR_OVERFLOW.  0 = default (65536).  With the ray exchange (schedule 2,
+                            exchange != 1) every lane that takes over part of a pixel's ray tree counts from 1 again, so
+                            the cap bounds the work of one lane, not the size of the tree */
     uint32_t fp_mode;    /* 0 = strict: no FMA contraction, IEEE division and sqrt, the reference's operation order (the
-                            parity flavour).  1 = fast: contraction and shared reciprocals allowed; within 1/255 per
-                            8-bit channel of strict, not bit-equal */
+                            parity flavour).  1 = fast: contraction and shared reciprocals allowed; not bit-equal: every
+                            colour is within ~1e-10 of strict as long as each ray hits the same primitive in both
+                            flavours; a ray that grazes an edge may not, and mirrors / glass carry that difference on
+                            (measured: 0 channels off by more than 1/255 on the scenes without glass, a few pixels per
+                            frame on those with it -- DESIGN.md section 5) */
     uint32_t reserved[6];
 } rtc_render_opts;
 
