@@ -372,3 +372,30 @@ def test_edge_cases_empty_world_tiny_cameras_unbounded_only_and_depth_limit():
         assert not np.isnan(scene.render(depth=0)).any()
     finally:
         scene.close()
+
+
+def test_large_canvas_download_is_exact_whole_and_tiled():
+    # rtc_render moves a 4K canvas (199 MB) to the caller through three pinned staging buffers with several host
+    # threads copying out of them: every byte must land where rtc_render_device put it, for the whole frame and for
+    # an interleaved row-tile share (whose rows are scattered into the full-size canvas)
+    import torch
+    w, h = 3840, 2160
+    objs = [_floor(color=(0.9, 0.8, 0.7), reflectivity=0.2),
+            rtc.Sphere(M.translation(0, 1, 0), rtc.Material(color=(0.2, 0.9, 0.4), reflectivity=0.3)),
+            rtc.Cube(M.scaling(0.6, 0.6, 0.6).rotate_y(0.5).translate(2.2, 0.6, 0.5), rtc.Material(color=(0.9, 0.3, 0.2)))]
+    scene = _cam(w, h).compile(rtc.World(objs, LIGHT), device=0)
+    try:
+        dev = torch.empty((h, w, 3), dtype=torch.float64, device="cuda:0")
+        scene.render_device(dev.data_ptr(), 0, schedule=1)
+        scene.check()
+        want = dev.cpu().numpy()
+        got = scene.render(schedule=1)
+        assert np.array_equal(got, want) and float(np.abs(got).sum()) > 0
+        tile = dict(tile_rows=8, tile_index=1, tile_count=3)
+        rows = scene.local_row_map(**tile)
+        part = scene.render(out=np.full((h, w, 3), -1.0), schedule=1, **tile)
+        assert np.array_equal(part[rows], want[rows])
+        others = np.setdiff1d(np.arange(h), rows)
+        assert np.all(part[others] == 0.0)  # rows of the other shares come back black (rtc_render clears the canvas)
+    finally:
+        scene.close()
