@@ -402,7 +402,11 @@ static int launch_on(Scene &s, DeviceReplica &r, const DRenderParams &p, const r
         s.have_last_stats = true;
     }
     r.last_work = work;
-    return (p.fast ? fastfp::launch_render : launch_render)(r.dscene, p, d_rgb, r.d_stats, work, r.n_cu,
+    DRenderParams pp = p;
+    // (the tile order was worked out for the whole frame: shares of a frame keep the raster order)
+    const bool whole = p.tile_count <= 1 && (size_t)p.tiles_x * p.tiles_y == s.tile_perm.size();
+    pp.tile_perm = (!p.persistent && whole) ? r.d_tile_perm : nullptr;
+    return (p.fast ? fastfp::launch_render : launch_render)(r.dscene, pp, d_rgb, r.d_stats, work, r.n_cu,
                                                             o.collect_stats != 0, st, &r.last_launch_id, refuse_oversize);
 }
 

@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     bool rendered = false;
     if (!PERSISTENT) {
         // static schedule: workgroup b renders tile b and nothing else
-        pix = blockIdx.x * 64u + lane;
+        pix = (prm.tile_perm ? prm.tile_perm[blockIdx.x] : blockIdx.x) * 64u + lane;
         init_pixel();
         rendered = alive;
     }

@@ -783,6 +783,71 @@ void Scene::build_bvh() {
 }
 
 // ---------------------------------------------------------------------------------------------
+// tile order of the static schedule
+// ---------------------------------------------------------------------------------------------
+// The static schedule launches one workgroup per 8x8 tile and the hardware starts them in index order.  A tile that
+// shows glass (a ray tree per pixel, depth 5) takes ~100 rounds of one wave; when it starts in the middle of the frame
+// the whole GPU waits for it at the end (cover.yaml at 1080p: 1.8 of 2.35 ms).  Longest job first: tiles are ordered
+// by what the camera sees in them -- bounds of transparent (weight 4) and reflective (weight 1) primitives projected
+// onto the canvas (camera.rs:41-59 read backwards) -- and rendered in that order.  A heuristic: it changes when a tile
+// starts, never what it computes.
+void Scene::build_tile_order() {
+    tile_perm.clear();
+    static const int enabled = getenv("RTC_TILE_SORT") ? atoi(getenv("RTC_TILE_SORT")) : 1;
+    const uint32_t tx = (hsize + 7u) / 8u, ty = (vsize + 7u) / 8u;
+    if (!enabled || (uint64_t)tx * ty < 2 || (uint64_t)tx * ty > (1u << 24)) return;
+    std::vector<int32_t> diff((size_t)(tx + 1) * (ty + 1), 0);  // 2-d difference array of the weights
+    bool any = false;
+    for (size_t pi = 0; pi < prims.size(); pi++) {
+        if (!prim_bounded[pi] || prims[pi].material < 0) continue;
+        const DMaterial &m = dmaterials[(size_t)prims[pi].material];
+        const int32_t w = (m.transparency != 0.0 ? 4 : 0) + (m.reflectivity != 0.0 ? 1 : 0);
+        if (w == 0) continue;
+        const Bounds &b = prim_bounds[pi];
+        double x0 = INF, x1 = -INF, y0 = INF, y1 = -INF;
+        bool behind = false;
+        for (int c = 0; c < 8 && !behind; c++) {
+            const double p[3] = {(c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1], (c & 4) ? b.hi[2] : b.lo[2]};
+            double q[3];
+            for (int r = 0; r < 3; r++) q[r] = view.m[r][0] * p[0] + view.m[r][1] * p[1] + view.m[r][2] * p[2] + view.m[r][3];
+            if (!(q[2] < -1e-6)) {  // at or behind the eye (the camera looks down -z): anywhere on the canvas
+                behind = true;
+                break;
+            }
+            const double px = (cam.half_width - q[0] / -q[2]) / cam.pixel_size;
+            const double py = (cam.half_height - q[1] / -q[2]) / cam.pixel_size;
+            x0 = std::min(x0, px), x1 = std::max(x1, px), y0 = std::min(y0, py), y1 = std::max(y1, py);
+        }
+        if (behind) x0 = y0 = 0.0, x1 = (double)hsize, y1 = (double)vsize;
+        if (!(x1 >= 0.0 && y1 >= 0.0 && x0 <= (double)hsize && y0 <= (double)vsize)) continue;  // off the canvas (or NaN)
+        const uint32_t t0x = (uint32_t)(std::max(0.0, std::floor(x0)) / 8.0), t0y = (uint32_t)(std::max(0.0, std::floor(y0)) / 8.0);
+        const uint32_t t1x = std::min(tx - 1u, (uint32_t)(std::min((double)hsize, x1) / 8.0));
+        const uint32_t t1y = std::min(ty - 1u, (uint32_t)(std::min((double)vsize, y1) / 8.0));
+        if (t0x > t1x || t0y > t1y) continue;
+        diff[(size_t)t0y * (tx + 1) + t0x] += w, diff[(size_t)t0y * (tx + 1) + t1x + 1] -= w;
+        diff[(size_t)(t1y + 1) * (tx + 1) + t0x] -= w, diff[(size_t)(t1y + 1) * (tx + 1) + t1x + 1] += w;
+        any = true;
+    }
+    if (!any) return;
+    std::vector<int32_t> score((size_t)tx * ty);
+    std::vector<int32_t> col(tx + 1, 0);
+    int32_t lo = INT32_MAX, hi = INT32_MIN;
+    for (uint32_t y = 0; y < ty; y++) {
+        int32_t run = 0;
+        for (uint32_t x = 0; x < tx; x++) {
+            col[x] += diff[(size_t)y * (tx + 1) + x];
+            run += col[x];
+            score[(size_t)y * tx + x] = run;
+            lo = std::min(lo, run), hi = std::max(hi, run);
+        }
+    }
+    if (lo == hi) return;  // every tile alike: raster order
+    tile_perm.resize((size_t)tx * ty);
+    for (uint32_t t = 0; t < tx * ty; t++) tile_perm[t] = t;
+    std::stable_sort(tile_perm.begin(), tile_perm.end(), [&](uint32_t a, uint32_t c) { return score[a] > score[c]; });
+}
+
+// ---------------------------------------------------------------------------------------------
 // upload
 // ---------------------------------------------------------------------------------------------
 
@@ -924,6 +989,8 @@ int Scene::upload(int dev, DeviceReplica &rep) {
         if (!m.casts_shadow) dscene.all_cast_shadow = 0;
         if (m.pattern >= 0) dscene.any_pattern = 1;
     }
+    rep.d_tile_perm = nullptr;
+    if (!tile_perm.empty() && (rc = upload_vec(rep, tile_perm, rep.d_tile_perm))) return rc;
     std::vector<uint64_t> zeros(ST_COUNT, 0);
     const uint64_t *dst = nullptr;
     if ((rc = upload_vec(rep, zeros, dst))) return rc;
@@ -978,6 +1045,7 @@ int Scene::commit(const int *devices, uint32_t n_devices) {
         return RTC_ERR_INVALID;
     }
     build_bvh();
+    build_tile_order();
     device = -1;
     if (n_devices > 0 && devices[0] >= 0) {
         reps.resize(n_devices);

@@ -54,6 +54,7 @@ struct DeviceReplica {
     void *stream = nullptr;       // replicas of a multi-device scene render on a stream of their own
     double *d_canvas = nullptr;   // rtc_render's device canvas: allocated at the first call, kept, grown on demand
     size_t canvas_bytes = 0;
+    const uint32_t *d_tile_perm = nullptr;  // Scene::tile_perm on this device (or null)
     uint32_t last_launch_id = 0;  // id of the most recent launch and the work buffer it used (overflow flag)
     unsigned *last_work = nullptr;
 };
@@ -106,6 +107,9 @@ struct Scene {
     // ---- device state: reps[0] is the primary device (`device`), where a multi-device frame is assembled ----
     std::vector<DeviceReplica> reps;
     uint64_t device_bytes = 0;
+    // whole-frame tile order of the static schedule: tiles that show transparent / reflective objects first (empty: raster)
+    std::vector<uint32_t> tile_perm;
+    void build_tile_order();
     void *h_stage[3] = {nullptr, nullptr, nullptr};  // pinned staging buffers of rtc_render's device-to-host copy
     size_t stage_bytes = 0;
     rtc_stats last_stats{};

@@ -266,6 +266,11 @@ struct DRenderParams {
     uint32_t max_rays;          // rays one lane may trace for one pixel (or adopted subtree) before it gives up
     uint32_t fast;              // rtc_render_opts.fp_mode: 1 selects the kernels compiled with FMA contraction
     uint32_t refuse_oversize;   // host only: 1 = a grid beyond RTC_MAX_WAVES with the exchange on is an error (2 = it was)
+    uint32_t pad0;
+    // static schedule, whole frame: workgroup b renders tile tile_perm[b] -- the tiles that show transparent or reflective
+    // objects first, because a frame of few such objects lasts as long as its slowest tile and that tile should not
+    // start last (null: workgroup b renders tile b)
+    const uint32_t *tile_perm;
 };
 
 // device-side counters, one uint64 each (index constants)
