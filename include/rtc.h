@@ -216,7 +216,9 @@ int rtc_scene_check(rtc_scene *scene);
 /* Device-resident variant for callers that own device memory and a stream (torch, RCCL pipelines):
  * d_rgb is a DEVICE pointer to rtc_local_rows(...)*hsize*3 doubles; this rank's rows are stored compactly in
  * ascending canvas-row order (every row, including an all-black last canvas row if it is owned).
- * Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream); allocates nothing. */
+ * Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).  Whole-frame calls allocate nothing; the FIRST
+ * call with a given share of the frame (tile_rows / tile_index / tile_count) uploads that share's tile order (one small
+ * hipMalloc + synchronous copy), later calls with the same share allocate nothing. */
 int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream);
 /* rtc_render_device for callers that cannot allocate and cannot rely on memory the library allocated for this
  * scene's launches: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO
@@ -227,7 +229,8 @@ int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_r
  * GPU, held until the process ends.  Limits: collect_stats is refused; frames beyond 2^26 8x8 tiles are refused (as by
  * every entry point); the persistent grid is capped at RTC_STATIC_SCRATCH_WAVES resident waves (MI355X: 3072).  Every
  * scene on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race -- serialise
- * them.  The call itself makes no hipMalloc / hipFree / allocating runtime call. */
+ * them.  The call itself makes no hipMalloc / hipFree / allocating runtime call (a share of the frame whose tile order
+ * has not been uploaded by an earlier rtc_render / rtc_render_device call is rendered in raster order). */
 #define RTC_STATIC_SCRATCH_WAVES 4096u
 #define RTC_STATIC_SCRATCH_BYTES (36864u + RTC_STATIC_SCRATCH_WAVES * 64u * (80u + 512u))
 int rtc_render_device_static(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream);

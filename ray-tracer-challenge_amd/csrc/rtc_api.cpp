@@ -405,7 +405,41 @@ static int launch_on(Scene &s, DeviceReplica &r, const DRenderParams &p, const r
     DRenderParams pp = p;
     // (the tile order was worked out for the whole frame: shares of a frame keep the raster order)
     const bool whole = p.tile_count <= 1 && (size_t)p.tiles_x * p.tiles_y == s.tile_perm.size();
-    pp.tile_perm = (!p.persistent && whole) ? r.d_tile_perm : nullptr;
+    pp.tile_perm = whole ? r.d_tile_perm : nullptr;
+    if (!whole && p.tile_count > 1 && !s.tile_score.empty()) {
+        // a share of the frame (one rank's or one replica's interleaved row tiles): its tiles in the order of the whole
+        // frame's weights.  Built and uploaded at the first launch with this share -- the one allocation a render entry
+        // point makes after commit, which is why the allocation-free entry point only uses an order that exists already.
+        const bool have = r.d_share_perm && r.share_key[0] == p.tile_rows && r.share_key[1] == p.tile_index &&
+                          r.share_key[2] == p.tile_count && r.n_share_perm == p.tiles_x * p.tiles_y;
+        if (!have && !refuse_oversize) {
+            const uint32_t n = p.tiles_x * p.tiles_y, gx = (s.hsize + 7u) / 8u, gy = (s.vsize + 7u) / 8u;
+            std::vector<int32_t> score(n);
+            for (uint32_t ty = 0; ty < p.tiles_y; ty++) {
+                const uint32_t l = 8u * ty, k = l / p.tile_rows;
+                const uint32_t y = (k * p.tile_count + p.tile_index) * p.tile_rows + l % p.tile_rows;  // canvas row
+                const uint32_t row = std::min(y / 8u, gy - 1u);
+                for (uint32_t tx = 0; tx < p.tiles_x; tx++) score[(size_t)ty * p.tiles_x + tx] = s.tile_score[(size_t)row * gx + std::min(tx, gx - 1u)];
+            }
+            std::vector<uint32_t> perm(n);
+            for (uint32_t t = 0; t < n; t++) perm[t] = t;
+            std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t c) { return score[a] > score[c]; });
+            if (r.n_share_perm < n) {
+                if (r.d_share_perm) (void)hipFree(r.d_share_perm);
+                r.d_share_perm = nullptr, r.n_share_perm = 0;
+                if (hipMalloc((void **)&r.d_share_perm, sizeof(uint32_t) * n) != hipSuccess) r.d_share_perm = nullptr;
+            }
+            if (r.d_share_perm && hipMemcpy(r.d_share_perm, perm.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice) == hipSuccess) {
+                r.n_share_perm = n;
+                r.share_key[0] = p.tile_rows, r.share_key[1] = p.tile_index, r.share_key[2] = p.tile_count;
+                pp.tile_perm = r.d_share_perm;
+            } else {
+                r.share_key[2] = 0;  // (no order: the raster order is always correct)
+            }
+        } else if (have) {
+            pp.tile_perm = r.d_share_perm;
+        }
+    }
     return (p.fast ? fastfp::launch_render : launch_render)(r.dscene, pp, d_rgb, r.d_stats, work, r.n_cu,
                                                             o.collect_stats != 0, st, &r.last_launch_id, refuse_oversize);
 }

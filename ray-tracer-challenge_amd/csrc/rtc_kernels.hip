@@ -935,7 +935,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     unsigned pix = 0;               // tile * 64 + position in tile
     // wave-uniform: unassigned pixels of the tile in hand.  Wave b starts with tile b (no counter traffic while
     // the grid starts up); tiles from prm.dyn_base (= the grid size) on are drawn from the counters.
-    unsigned r_next = blockIdx.x * 64u, r_end = r_next + 64u;
+    unsigned r_next = (PERSISTENT && prm.tile_perm ? prm.tile_perm[blockIdx.x] : blockIdx.x) * 64u, r_end = r_next + 64u;
     const unsigned n_dynamic = PERSISTENT ? n_tiles - prm.dyn_base : 0u;
     unsigned shard = blockIdx.x % RTC_SHARDS, shards_tried = 0;
     bool exhausted = n_dynamic == 0u;  // wave-uniform: every counter ran past its last tile
@@ -1153,6 +1153,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                             exhausted = true;
                             break;
                         }
+                        if (prm.tile_perm) t = prm.tile_perm[t];  // (heaviest tiles first, see the static schedule)
                         r_next = t * 64u, r_end = r_next + 64u;
                     }
                     dead = __ballot(!alive);

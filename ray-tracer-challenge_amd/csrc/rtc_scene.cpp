@@ -52,6 +52,7 @@ void Scene::release_device() {
         DeviceGuard g(r.device);
         for (void *p : r.allocs) (void)hipFree(p);
         if (r.d_canvas) (void)hipFree(r.d_canvas);
+        if (r.d_share_perm) (void)hipFree(r.d_share_perm);
         if (r.ev_start) (void)hipEventDestroy((hipEvent_t)r.ev_start);
         if (r.ev_stop) (void)hipEventDestroy((hipEvent_t)r.ev_stop);
         if (r.stream) (void)hipStreamDestroy((hipStream_t)r.stream);
@@ -792,7 +793,7 @@ void Scene::build_bvh() {
 // onto the canvas (camera.rs:41-59 read backwards) -- and rendered in that order.  A heuristic: it changes when a tile
 // starts, never what it computes.
 void Scene::build_tile_order() {
-    tile_perm.clear();
+    tile_perm.clear(), tile_score.clear();
     static const int enabled = getenv("RTC_TILE_SORT") ? atoi(getenv("RTC_TILE_SORT")) : 1;
     const uint32_t tx = (hsize + 7u) / 8u, ty = (vsize + 7u) / 8u;
     if (!enabled || (uint64_t)tx * ty < 2 || (uint64_t)tx * ty > (1u << 24)) return;
@@ -845,6 +846,7 @@ void Scene::build_tile_order() {
     tile_perm.resize((size_t)tx * ty);
     for (uint32_t t = 0; t < tx * ty; t++) tile_perm[t] = t;
     std::stable_sort(tile_perm.begin(), tile_perm.end(), [&](uint32_t a, uint32_t c) { return score[a] > score[c]; });
+    tile_score.swap(score);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -55,6 +55,11 @@ struct DeviceReplica {
     double *d_canvas = nullptr;   // rtc_render's device canvas: allocated at the first call, kept, grown on demand
     size_t canvas_bytes = 0;
     const uint32_t *d_tile_perm = nullptr;  // Scene::tile_perm on this device (or null)
+    // the same order for the most recent SHARE of the frame rendered here (rtc_render_opts.tile_*): built at the first
+    // launch with that share, kept until another share is asked for
+    uint32_t share_key[3] = {0, 0, 0};  // tile_rows, tile_index, tile_count
+    uint32_t *d_share_perm = nullptr;
+    uint32_t n_share_perm = 0;
     uint32_t last_launch_id = 0;  // id of the most recent launch and the work buffer it used (overflow flag)
     unsigned *last_work = nullptr;
 };
@@ -109,6 +114,7 @@ struct Scene {
     uint64_t device_bytes = 0;
     // whole-frame tile order of the static schedule: tiles that show transparent / reflective objects first (empty: raster)
     std::vector<uint32_t> tile_perm;
+    std::vector<int32_t> tile_score;  // the weights the order was sorted by, per whole-frame tile (empty: all alike)
     void build_tile_order();
     void *h_stage[3] = {nullptr, nullptr, nullptr};  // pinned staging buffers of rtc_render's device-to-host copy
     size_t stage_bytes = 0;

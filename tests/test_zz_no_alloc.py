@@ -55,7 +55,8 @@ def test_static_scratch_entry_point_equals_render_device_twice_in_a_row():
         # the overflow flag lives in the shared array too: a capped launch reports, the next clean one does not
         scene, cam = scenes[1]
         buf = torch.zeros((cam.vsize, cam.hsize, 3), dtype=torch.float64, device="cuda:0")
-        scene.render_device_static(buf.data_ptr(), 0, schedule=2, max_rays_per_pixel=6)
+        # (exchange off: the cap then bounds a whole pixel's ray tree, whatever the timing)
+        scene.render_device_static(buf.data_ptr(), 0, schedule=2, max_rays_per_pixel=6, exchange=1)
         with pytest.raises(rtc._native.RtcError) as e:
             scene.check()
         assert e.value.code == rtc._native.ERR_OVERFLOW
