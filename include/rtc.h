@@ -80,7 +80,11 @@ typedef struct rtc_render_opts {
     uint32_t tile_count; /* number of ranks (1 = everything) */
     uint32_t use_bvh;    /* 0 = auto, 1 = force BVH traversal, 2 = force brute-force linear scan */
     uint32_t collect_stats; /* 1 = run the counting variant of the kernel and fill the ray/test counters */
-    uint32_t schedule;   /* 0 = auto, 1 = one workgroup per 8x8 tile, 2 = persistent grid with lane refill */
+    uint32_t schedule;   /* 0 = auto (1 or 2 by scene), 1 = one workgroup per 8x8 tile, 2 = persistent grid with lane
+                            refill, 3 = wavefront (experimental, never chosen by auto: queues of rays in device memory,
+                            one traversal kernel and one shading kernel per kind of ray and generation; same pixels
+                            within ~1e-14; the call is synchronous, allocates its queues at the first use -- 5.4 KB per
+                            pixel -- and is refused by rtc_render_device_static and with collect_stats) */
     uint32_t exchange;   /* persistent schedule only.  0 = auto (on): at the end of a frame lanes and waves without work
                             take over waiting rays of busy ones and ADD their part to the pixel with f64 atomics -- the
                             order of those few additions is timing dependent (observed <= 2e-15).  1 = off: every pixel

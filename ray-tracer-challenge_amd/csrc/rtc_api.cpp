@@ -332,6 +332,14 @@ static int resolve_params(Scene &s, const rtc_render_opts *opts_in, DRenderParam
         set_error("fp_mode %u: 0 = strict, 1 = fast", o.fp_mode);
         return RTC_ERR_INVALID;
     }
+    if (o.schedule > 3) {
+        set_error("schedule %u: 0 = auto, 1 = workgroup per tile, 2 = persistent, 3 = wavefront", o.schedule);
+        return RTC_ERR_INVALID;
+    }
+    if (o.schedule == 3 && o.collect_stats) {
+        set_error("the wavefront schedule has no counting variant (collect_stats)");
+        return RTC_ERR_INVALID;
+    }
     p = DRenderParams{};
     p.depth = o.depth;
     p.tile_rows = o.tile_rows, p.tile_index = o.tile_index, p.tile_count = o.tile_count;
@@ -392,8 +400,57 @@ static void fill_stats(Scene &s, const std::vector<uint64_t> &c, rtc_stats &st) 
 }
 
 // one asynchronous launch on replica r with `work` as the grid's work buffer
+// Queues of the wavefront schedule, allocated at the first use: twelve items per pixel and kind (RTC_WF_CAP_FACTOR) --
+// the generations of a glass-heavy frame grow to ten times its pixel count before they shrink (stress scene:
+// profiles/r2_ab/r2_wf_trace.txt) -- at 448 bytes per item over both queues.  A frame whose queues would pass 96 GB is
+// refused: render it in shares of its rows (rtc_render_opts.tile_*).
+static int ensure_wavefront(DeviceReplica &r, size_t pixels) {
+    static const unsigned factor_env = getenv("RTC_WF_CAP_FACTOR") ? (unsigned)atoi(getenv("RTC_WF_CAP_FACTOR")) : 0u;
+    const size_t want = std::max<size_t>(pixels * (factor_env ? factor_env : 12u), (size_t)1 << 20);
+    const size_t bytes = 3 * want * (2 * (sizeof(WfRay) + sizeof(WfCtx)) + sizeof(WfHit));
+    if (want >= ((size_t)1 << 30) || bytes > ((size_t)96 << 30)) {
+        set_error("wavefront schedule: %zu pixels need %zu GB of queues; render the frame in shares of its rows", pixels,
+                  bytes >> 30);
+        return RTC_ERR_INVALID;
+    }
+    WfBuffers &b = r.wf;
+    if (b.cap >= want) return RTC_OK;
+    for (int k = 0; k < 2; k++) {
+        if (b.rays[k]) (void)hipFree(b.rays[k]);
+        if (b.ctx[k]) (void)hipFree(b.ctx[k]);
+        b.rays[k] = nullptr, b.ctx[k] = nullptr;
+    }
+    if (b.hits) (void)hipFree(b.hits);
+    b.hits = nullptr, b.cap = 0;
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; k++)
+        ok = hipMalloc((void **)&b.rays[k], 3 * want * sizeof(WfRay)) == hipSuccess &&
+             hipMalloc((void **)&b.ctx[k], 3 * want * sizeof(WfCtx)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&b.hits, 3 * want * sizeof(WfHit)) == hipSuccess;
+    if (ok && !b.counts) ok = hipMalloc(&b.counts, 256) == hipSuccess && hipHostMalloc(&b.h_counts, 256, hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        set_error("wavefront schedule: allocating queues for %zu items per kind failed: %s", want,
+                  hipGetErrorString(hipGetLastError()));
+        return RTC_ERR_HIP;
+    }
+    b.cap = (uint32_t)want;
+    return RTC_OK;
+}
+
 static int launch_on(Scene &s, DeviceReplica &r, const DRenderParams &p, const rtc_render_opts &o, double *d_rgb,
                      unsigned *work, hipStream_t st, bool refuse_oversize = false) {
+    if (o.schedule == 3) {
+        // the wavefront schedule: a sequence of launches driven from here, complete when the call returns
+        if (refuse_oversize) {
+            set_error("the wavefront schedule allocates its queues: not through the allocation-free entry point");
+            return RTC_ERR_INVALID;
+        }
+        int rc = ensure_wavefront(r, (size_t)p.local_rows * s.hsize);
+        if (rc) return rc;
+        r.last_work = work;
+        return (p.fast ? fastfp::launch_wavefront : launch_wavefront)(r.dscene, p, d_rgb, r.wf, work, r.n_cu, st,
+                                                                      &r.last_launch_id, s.hsize, &r.wf_generations);
+    }
     if (o.collect_stats) {
         if (hipMemsetAsync(r.d_stats, 0, sizeof(uint64_t) * ST_COUNT, st) != hipSuccess) {
             set_error("hipMemsetAsync(stats) failed");

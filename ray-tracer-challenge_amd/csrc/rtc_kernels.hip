@@ -1315,347 +1315,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         // resumable: its state (node in hand, leaf run, stack) lives in registers / LDS across (C), so the wave
         // can leave (B) to serve finished lanes while long rays are still on their way, and re-enter.
         // =====================================================================================
-        if (alive && !in_pass) {
-            // ---- (A) phase 1: lockstep walk over the always-tested list (i, L.* are wave-uniform) ----
-            const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
-            int u_cache = -1;
-            Ray u_ray = ray;  // lockstep list: the cache key is wave-uniform and lives only inside this loop
-            for (int i = 0; i < n_lin; i++) {
-                const __attribute__((address_space(4))) DLeaf &L = lin[i];
-                Ray r = ray;
-                if (GROUPS && L.anc_len > 0) {
-                    if (L.anc_id != u_cache) {
-                        u_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
-                        u_cache = L.anc_id;
-                        CNT(ST_XFORM, L.anc_len);  // Group::intersect transforms the ray once per group
-                    }
-                    r = u_ray;
-                }
-                if (PATTERNS && (L.closed & RTC_LEAF_IN_CSG)) continue;  // (brute-force list: reached through its tree)
-                if (PATTERNS && L.type == PT_CSG) {
-                    if (!(any_hit && T.prim >= 0) && !isect_csg(s, L.anc_off, ray, T)) flag_overflow();
-                    continue;
-                }
-                if (!(any_hit && T.prim >= 0)) {
-                    CNT(ST_XFORM, L.type < PT_TRIANGLE ? 1 : 0);  // the shape's own Ray::transform
-                    CNT(ST_PRIM0 + L.type, 1);
-                    isect_leaf(L, r, T);
-                }
-            }
-            if (RAY_CACHE) cache_ray = u_ray;
-            if (RAY_CACHE || STATS) cache_id = u_cache;
-            if (use_bvh && s.n_bounded > 0 && !(any_hit && T.prim >= 0)) {
-                // ---- phase 2 set-up: ordered BVH traversal, leaves tested as they are reached ----
-                V3 inv_d, oi;
-                inv_d = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
-                oi = mk(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z);
-                // slab plane of cell index q along axis a: t = (org + q * cell - o) / d = q * (cell / d) + (org / d + oi)
-                // (f32 nodes: the planes themselves, t = plane * inv_d + oi, |plane| <= the root box's largest coordinate)
-                if (QNODES && !RTC_QF32) {
-                    slab_axis(s.q_cell[0] * inv_d.x, fma(s.q_org[0], inv_d.x, oi.x), 65535., slab_ray.ax, slab_ray.bx);
-                    slab_axis(s.q_cell[1] * inv_d.y, fma(s.q_org[1], inv_d.y, oi.y), 65535., slab_ray.ay, slab_ray.by);
-                    slab_axis(s.q_cell[2] * inv_d.z, fma(s.q_org[2], inv_d.z, oi.z), 65535., slab_ray.az, slab_ray.bz);
-                } else {
-                    slab_axis(inv_d.x, oi.x, 1.000001 * fmax(fabs(s.root_min[0]), fabs(s.root_max[0])), slab_ray.ax, slab_ray.bx);
-                    slab_axis(inv_d.y, oi.y, 1.000001 * fmax(fabs(s.root_min[1]), fabs(s.root_max[1])), slab_ray.ay, slab_ray.by);
-                    slab_axis(inv_d.z, oi.z, 1.000001 * fmax(fabs(s.root_min[2]), fabs(s.root_max[2])), slab_ray.az, slab_ray.bz);
-                }
-                pos = 0, end = 0;
-                stack[0] = RTC_NO_NODE, sb = 1;  // bottom of the stack: "pass finished"
-                double tn;
-                CNT(ST_BOX, 1);
-                if (slab(s.root_min, s.root_max, inv_d, oi, (T.mode == MODE_CONTAINER) ? -inf : 0., T.lim, tn)) {
-                    cur = s.root_ref;
-                    in_pass = true;
-                }
-            }
-        }
-        STAGE_END(ST_CYC_START);
-        // ---- (B) traversal steps ----
-        for (;;) {
-            const unsigned long long act = __ballot(alive && in_pass);
-            if (!act) break;
-            WCNT(ST_ROUNDS_TRAVERSE, 1);
-            WCNT(ST_LANES_TRAVERSE, __popcll(act));
-            if (PERSISTENT) {
-                // leave the traversal once enough lanes wait to be served (pass finished -> state machine, or free
-                // and a pixel is available): the state machine then runs for a batch of lanes, not for each one
-                unsigned long long idle = __ballot(alive && !in_pass);
-                const unsigned long long dead = __ballot(!alive);
-                if (!(exhausted && r_next == r_end)) {
-                    if ((unsigned)__popcll(dead) >= prm.refill_min) idle |= dead;
-                } else if (idle != 0ull || (prm.share && __ballot(alive && sp > 0) != 0ull)) {
-                    // tail: free lanes can take over a waiting ray, and in a wave that is mostly empty a finished lane
-                    // is served at once -- what is left of the frame is a chain of dependent rays, not throughput.
-                    // (Without the exchange a waiting ray is no reason to leave: nobody could take it, and a wave
-                    // that left for it would come straight back -- for ever.)
-                    idle |= dead;
-                }
-                if ((unsigned)__popcll(idle) >= prm.stay_min) break;
-            }
-            if (alive && in_pass) {
-#ifdef RTC_POP_PROBE
-#define RTC_PROBE_PUSH() do { if (sb < RTC_BVH_STACK) probe_t[sb] = probe_push; } while (0)
-#define RTC_PROBE_POP(v)                                                                                 \
-    do {                                                                                                 \
-        if (STATS && (v) != RTC_NO_NODE && sb < RTC_BVH_STACK) {                                         \
-            cnt.c[ST_PRIM0 + 2] += 1;                                                                    \
-            if (probe_t[sb] > f32_above(T.lim)) cnt.c[ST_PRIM0 + 3] += 1;                                \
-            if (probe_t[sb] > f32_above(T.lim) && (v) < 0) cnt.c[ST_PRIM0 + 4] += 1 + ((~(v)) & 7);      \
-        }                                                                                                \
-    } while (0)
-#else
-#define RTC_PROBE_PUSH() do { } while (0)
-#define RTC_PROBE_POP(v) do { } while (0)
-#endif
-#define RTC_PUSH(v)                                                 \
-    do {                                                            \
-        RTC_PROBE_PUSH();                                           \
-        if (sb < RTC_LDS_STACK)                                     \
-            stack[sb * RTC_WAVE] = (v);                             \
-        else if (sb < RTC_BVH_STACK)                                \
-            deep_stack[sb - RTC_LDS_STACK] = (v);                   \
-        else                                                        \
-            flag_overflow();                                        \
-        sb++;                                                       \
-    } while (0)
-#define RTC_POP(v)                                                                                   \
-    do {                                                                                             \
-        sb--;                                                                                        \
-        (v) = stack[(sb < RTC_LDS_STACK ? sb : RTC_LDS_STACK - 1) * RTC_WAVE];                       \
-        if (sb >= RTC_LDS_STACK) (v) = deep_stack[(sb < RTC_BVH_STACK ? sb : RTC_BVH_STACK - 1) - RTC_LDS_STACK]; \
-        RTC_PROBE_POP(v);                                                                            \
-    } while (0)
-                const bool any_hit = (T.mode == MODE_SHADOW) && s.all_cast_shadow;
-                const double lo = (T.mode == MODE_CONTAINER) ? -inf : 0.;
-                for (int step = 0; step < RTC_STEPS_PER_CHECK && in_pass; step++) {
-                    // A step is a primitive test for lanes standing at a leaf and a short descent for the others.
-                    // The primitive test is the longer half: it only runs once enough lanes wait for it (or no
-                    // lane has nodes left to visit), the waiting lanes sit the step out.
-                    const bool at_leaf = pos < end;
-                    const unsigned n_leaf = (unsigned)__popcll(__ballot(at_leaf));
-                    const unsigned n_node = (unsigned)__popcll(__ballot(!at_leaf));
-                    if (at_leaf && n_node != 0u && n_leaf * prm.leaf_den < n_leaf + n_node) continue;
-#ifdef RTC_TIMING_ONLY
-                    if (STATS) {  // lane participation of the two halves of a step (ballots: the lanes still here)
-                        const unsigned long long lm = __ballot(at_leaf), nm = __ballot(!at_leaf);
-                        const unsigned first = (unsigned)__ffsll((long long)(lm | nm)) - 1u;
-                        if (lane == first) {
-                            if (nm) cnt.c[ST_PRIM0 + 2] += 1, cnt.c[ST_PRIM0 + 3] += __popcll(nm);
-                            if (lm) cnt.c[ST_PRIM0 + 4] += 1, cnt.c[ST_PRIM0 + 5] += __popcll(lm);
-                        }
-                    }
-#endif
-                    if (at_leaf && QNODES && (pos & RTC_LEAF_COMPACT)) {
-                        // sphere with a diagonal + translation inverse: 64-byte record, the off-diagonal zeros are
-                        // rebuilt with their signs and the arithmetic is the general sphere's (same bits)
-                        const DLeafS &L = s.leaves_s[(pos++) & (RTC_LEAF_COMPACT - 1)];
-                        CNT(ST_XFORM, 1);
-                        CNT(ST_PRIM0 + PT_SPHERE, 1);
-                        // Ray::transform by a matrix whose off-diagonal entries are (signed) zeros.  The reference's
-                        // ((m00 x + m01 y) + m02 z) + m03 (matrix.rs:339-343) adds +-0 * y and +-0 * z to m00 x: for
-                        // finite y, z that changes nothing but, when m00 x is itself a zero, the SIGN of that zero --
-                        // and a zero's sign can reach no comparison of the sphere test (squares, sums with non-zero
-                        // terms, t > 0, t < limit).  So the two products per component are all that is computed
-                        // (r1 rebuilt the zeros with their signs: 33 more f64 instructions per test).
-                        Ray q;
-                        q.o = mk(L.d[0] * ray.o.x + L.t[0], L.d[1] * ray.o.y + L.t[1], L.d[2] * ray.o.z + L.t[2]);
-                        q.d = mk(L.d[0] * ray.d.x, L.d[1] * ray.d.y, L.d[2] * ray.d.z);
-                        isect_sphere(q, T, L.prim);
-                        end_prim(T, L.prim);
-                        if (any_hit && T.prim >= 0) in_pass = false;
-                        continue;
-                    }
-                    if (at_leaf) {
-                        const DLeaf &L = s.leaves[pos++];
-                        if (PATTERNS && L.type == PT_CSG) {
-                            if (!isect_csg(s, L.anc_off, ray, T)) flag_overflow();
-                            if (any_hit && T.prim >= 0) in_pass = false;
-                            continue;
-                        }
-                        // Ray::transform down the ancestor chain, root first (shape.rs:2035).  Primitives of one
-                        // group share it: the ray in group space is cached per lane.
-                        Ray r = ray;
-                        if (GROUPS && L.anc_len > 0) {
-                            if (!RAY_CACHE) {
-                                r = through_ancestors(s, L.anc_off, L.anc_len, ray);
-                                if (STATS && L.anc_id != cache_id) {  // counted as the reference does: once per group
-                                    CNT(ST_XFORM, L.anc_len);
-                                    cache_id = L.anc_id;
-                                }
-                            } else {
-                                if (L.anc_id != cache_id) {
-                                    cache_ray = through_ancestors(s, L.anc_off, L.anc_len, ray);
-                                    cache_id = L.anc_id;
-                                    CNT(ST_XFORM, L.anc_len);
-                                }
-                                r = cache_ray;
-                            }
-                        }
-                        CNT(ST_XFORM, L.type < PT_TRIANGLE ? 1 : 0);
-                        CNT(ST_PRIM0 + L.type, 1);
-                        isect_leaf(L, r, T);
-                        if (any_hit && T.prim >= 0) in_pass = false;
-                        continue;
-                    }
-                    // ---- the node in hand, or the next one from the stack (whose bottom entry is RTC_NO_NODE: popping
-                    // it ends the pass, so an empty stack needs no test of its own) ----
-                    int ref = cur;
-#if RTC_BRANCHFREE
-                    // (the usual case -- every entry concerned sits in the LDS part of the stack -- is served without
-                    // a branch: the top of the stack is read whether or not it will be popped, selects do the rest)
-                    // (whether some lane's stack has grown out of its LDS part is asked once per step for the whole wave:
-                    // a scalar branch instead of exec-mask bookkeeping around the rare case; a step moves a stack by at
-                    // most RTC_NODES_PER_STEP entries)
-                    const bool shallow = QNODES && __ballot(sb + RTC_NODES_PER_STEP >= RTC_LDS_STACK) == 0ull;
-                    if (shallow) {
-                        const int top = stack[(sb - 1) * RTC_WAVE];
-                        const bool pop = ref == RTC_NO_NODE;
-                        ref = pop ? top : ref;
-                        sb -= pop ? 1 : 0;
-                    } else if (ref == RTC_NO_NODE)
-                        RTC_POP(ref);
-#else
-                    if (ref == RTC_NO_NODE) RTC_POP(ref);
-#endif
-                    // descend until a leaf is reached (bounded: the check above runs again after a few nodes)
-                    // the ray segment [lo, T.lim] in f32, rounded outward (T.lim only moves when a leaf test finds a hit,
-                    // never between the node visits of one step)
-                    const float hi32 = f32_above(T.lim), lo32 = (float)lo, lim_lo32 = f32_below(T.lim);
-                    for (int d = 0; d < ((QNODES && RTC_BVH4) ? RTC_NODES4_PER_STEP : RTC_NODES_PER_STEP) && ref >= 0; d++) {
-                        // containers pass: a subtree of paired primitives (spheres) matters only where its box
-                        // reaches the hit point -- a sphere wholly before the hit toggles in and out again
-                        const bool cont = T.mode == MODE_CONTAINER;
-                        const unsigned flags = cont ? s.node_flags[ref] : 0u;
-                        if (QNODES && RTC_BVH4) {
-                            // ---- four children per node (DBvhNode4): one 64-byte fetch per two levels of the binary tree ----
-                            CNT(ST_BOX, 4);
-                            const uint4 *np = (const uint4 *)(s.bvh4 + ref);
-                            const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];  // requested before any is used
-                            __builtin_amdgcn_sched_barrier(0);
-                            float t0, t1, t2, t3;
-                            const bool h0 = slab32_q(w0.x, w0.y, w0.z, slab_ray, (flags & 1u) ? lim_lo32 : lo32, hi32, t0);
-                            const bool h1 = slab32_q(w0.w, w1.x, w1.y, slab_ray, (flags & 2u) ? lim_lo32 : lo32, hi32, t1);
-                            // (slots 2 and 3 may be unused: their inverted boxes miss, and the reference is checked so
-                            // that no rounding, however far-fetched, can turn RTC_NO_CHILD into the node to visit)
-                            const bool h2 = slab32_q(w1.z, w1.w, w2.x, slab_ray, (flags & 4u) ? lim_lo32 : lo32, hi32, t2) &&
-                                            (int)w3.z != RTC_NO_CHILD;
-                            const bool h3 = slab32_q(w2.y, w2.z, w2.w, slab_ray, (flags & 8u) ? lim_lo32 : lo32, hi32, t3) &&
-                                            (int)w3.w != RTC_NO_CHILD;
-                            if (!(h0 || h1 || h2 || h3)) {
-                                RTC_POP(ref);
-                                continue;
-                            }
-                            // the nearest child that was hit goes first, the other hits wait on the stack
-                            const float inf32 = __builtin_inff();
-                            const float u0 = h0 ? t0 : inf32, u1 = h1 ? t1 : inf32, u2 = h2 ? t2 : inf32, u3 = h3 ? t3 : inf32;
-                            const float tmin = __builtin_fminf(__builtin_fminf(u0, u1), __builtin_fminf(u2, u3));
-                            const int sel = (h0 && u0 == tmin) ? 0 : (h1 && u1 == tmin) ? 1 : (h2 && u2 == tmin) ? 2 : 3;
-                            if (h3 && sel != 3) RTC_PUSH((int)w3.w);
-                            if (h2 && sel != 2) RTC_PUSH((int)w3.z);
-                            if (h1 && sel != 1) RTC_PUSH((int)w3.y);
-                            if (h0 && sel != 0) RTC_PUSH((int)w3.x);
-                            ref = sel == 0 ? (int)w3.x : sel == 1 ? (int)w3.y : sel == 2 ? (int)w3.z : (int)w3.w;
-                            continue;
-                        }
-                        float tl, tr;
-                        CNT(ST_BOX, 2);
-#ifdef RTC_MODE_PROBE  // measurement only: box tests by pass kind in the cube / cylinder / cone counters
-                        CNT(ST_PRIM0 + 2 + T.mode, 2);
-#endif
-                        bool hl, hr;
-                        int cl, cr;
-                        if (QNODES && !RTC_QF32) {
-                            const uint4 *np = (const uint4 *)(s.bvh_q + ref);
-#if RTC_LDS_TOP
-                            uint4 w0, w1;
-                            if (ref < n_top)
-                                w0 = top_nodes[2 * ref], w1 = top_nodes[2 * ref + 1];
-                            else
-                                w0 = np[0], w1 = np[1];
-#else
-                            const uint4 w0 = np[0], w1 = np[1];  // both halves requested before either is used
-#endif
-                            __builtin_amdgcn_sched_barrier(0);
-#if RTC_PREFETCH
-                            // Both children's records are requested the moment their references arrive, while this
-                            // node's boxes are still being tested: whichever child is visited next (now or from the
-                            // stack) then finds its line on the way or in the cache.  The words loaded are never used;
-                            // they are "consumed" one visit later, when the wait for that visit's own node has covered
-                            // them anyway (vector loads return in order).
-                            asm volatile("" ::"v"(pf0), "v"(pf1));
-                            {
-                                const int c0 = (int)w1.z, c1 = (int)w1.w;
-                                const char *a0 = child_line(s, c0), *a1 = child_line(s, c1);
-                                pf0 = *(const unsigned *)a0;
-                                pf1 = *(const unsigned *)a1;
-                            }
-#endif
-                            hl = slab32_q(w0.x, w0.y, w0.z, slab_ray, (flags & 1u) ? lim_lo32 : lo32, hi32, tl);
-                            hr = slab32_q(w0.w, w1.x, w1.y, slab_ray, (flags & 2u) ? lim_lo32 : lo32, hi32, tr);
-                            cl = (int)w1.z, cr = (int)w1.w;
-                        } else {
-                            const DBvhNode &n = s.bvh[ref];
-                            hl = slab32((f32x2){n.lx[0], n.lx[1]}, (f32x2){n.ly[0], n.ly[1]}, (f32x2){n.lz[0], n.lz[1]},
-                                        slab_ray, (flags & 1u) ? lim_lo32 : lo32, hi32, tl);
-                            hr = slab32((f32x2){n.rx[0], n.rx[1]}, (f32x2){n.ry[0], n.ry[1]}, (f32x2){n.rz[0], n.rz[1]},
-                                        slab_ray, (flags & 2u) ? lim_lo32 : lo32, hi32, tr);
-                            cl = n.left, cr = n.right;
-                        }
-                        // near child first, the far one waits on the stack (selects, not a branch per case)
-                        const bool left_first = tl <= tr;
-                        const bool take_left = hl && (!hr || left_first);
-#if RTC_BRANCHFREE
-                        if (shallow) {
-                            // the far child is stored above the top in any case (harmless when it is not pushed) and the
-                            // entry below it read in any case (used when both boxes are missed): two LDS operations and
-                            // five selects instead of three branches
-                            const int top = stack[(sb - 1) * RTC_WAVE];
-                            stack[sb * RTC_WAVE] = left_first ? cr : cl;
-                            const bool both = hl && hr, any = hl || hr;
-                            ref = any ? (take_left ? cl : cr) : top;
-                            sb += both ? 1 : (any ? 0 : -1);
-                            continue;
-                        }
-#endif
-#ifdef RTC_POP_PROBE
-                        probe_push = left_first ? tr : tl;
-#endif
-                        if (hl && hr) RTC_PUSH(left_first ? cr : cl);
-                        if (hl || hr)
-                            ref = take_left ? cl : cr;
-                        else
-                            RTC_POP(ref);
-                    }
-#if RTC_BRANCHFREE
-                    if (QNODES) {
-                        // what the descent arrived at: another internal node (carried to the next step), the stack's
-                        // bottom entry (every subtree has been dealt with) or a leaf's run of primitive records
-                        const bool done = ref == RTC_NO_NODE, leaf = ref < 0 && !done;
-                        const int code = ~ref;
-                        pos = leaf ? (code >> 3) : pos;
-                        end = leaf ? (code >> 3) + (code & 7) + 1 : end;
-                        cur = ref >= 0 ? ref : RTC_NO_NODE;
-                        in_pass = !done;
-                    } else
-#endif
-                    if (ref >= 0) {
-                        cur = ref;  // still an internal node: carry on at the next step
-                    } else if (ref == RTC_NO_NODE) {
-                        in_pass = false;  // the stack's bottom entry: every subtree has been dealt with
-                        cur = RTC_NO_NODE;
-                    } else {
-                        const int code = ~ref;
-                        pos = code >> 3;
-                        end = pos + (code & 7) + 1;
-                        cur = RTC_NO_NODE;
-                    }
-                }
-#undef RTC_PUSH
-#undef RTC_POP
-            }
-        }
-        STAGE_END(ST_CYC_TRAVERSE);
+#include "rtc_traverse.inc"
         if (STATS) {
             const unsigned long long m = __ballot(alive && !in_pass);
             if (m) {
@@ -2065,6 +1725,8 @@ int launch_render(const DScene &scene, const DRenderParams &params_in, double *d
     }
     return RTC_OK;
 }
+
+#include "rtc_wavefront.inc"
 
 RTC_FLAVOUR_END
 }  // namespace rtc

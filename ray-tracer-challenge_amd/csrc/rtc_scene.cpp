@@ -53,6 +53,13 @@ void Scene::release_device() {
         for (void *p : r.allocs) (void)hipFree(p);
         if (r.d_canvas) (void)hipFree(r.d_canvas);
         if (r.d_share_perm) (void)hipFree(r.d_share_perm);
+        for (int k = 0; k < 2; k++) {
+            if (r.wf.rays[k]) (void)hipFree(r.wf.rays[k]);
+            if (r.wf.ctx[k]) (void)hipFree(r.wf.ctx[k]);
+        }
+        if (r.wf.hits) (void)hipFree(r.wf.hits);
+        if (r.wf.counts) (void)hipFree(r.wf.counts);
+        if (r.wf.h_counts) (void)hipHostFree(r.wf.h_counts);
         if (r.ev_start) (void)hipEventDestroy((hipEvent_t)r.ev_start);
         if (r.ev_stop) (void)hipEventDestroy((hipEvent_t)r.ev_stop);
         if (r.stream) (void)hipStreamDestroy((hipStream_t)r.stream);

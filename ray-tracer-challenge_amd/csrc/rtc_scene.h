@@ -42,6 +42,16 @@ struct Bounds {
 
 // One copy of the committed scene on one GPU (the scene is replicated per device: SURVEY.md 8(e)), with the buffers
 // the render entry points keep between calls.
+// Queues of the wavefront schedule on one device (allocated at the first schedule-3 render, kept)
+struct WfBuffers {
+    WfRay *rays[2] = {nullptr, nullptr};  // queue 0 / 1: three regions of `cap` items (closest, containers, shadow)
+    WfCtx *ctx[2] = {nullptr, nullptr};
+    WfHit *hits = nullptr;                // answers of the queue being traversed
+    void *counts = nullptr;               // WfCounts (device)
+    void *h_counts = nullptr;             // its pinned host copy
+    uint32_t cap = 0;
+};
+
 struct DeviceReplica {
     int device = -1;
     DScene dscene{};
@@ -55,6 +65,8 @@ struct DeviceReplica {
     double *d_canvas = nullptr;   // rtc_render's device canvas: allocated at the first call, kept, grown on demand
     size_t canvas_bytes = 0;
     const uint32_t *d_tile_perm = nullptr;  // Scene::tile_perm on this device (or null)
+    WfBuffers wf;
+    uint32_t wf_generations = 0;  // generations of the most recent wavefront frame
     // the same order for the most recent SHARE of the frame rendered here (rtc_render_opts.tile_*): built at the first
     // launch with that share, kept until another share is asked for
     uint32_t share_key[3] = {0, 0, 0};  // tile_rows, tile_index, tile_count
@@ -153,6 +165,16 @@ namespace fastfp {  // the same kernels compiled with FMA contraction (rtc_rende
 int launch_render(const DScene &scene, const DRenderParams &params, double *d_rgb, uint64_t *d_stats,
                   unsigned *d_work, unsigned n_cu, bool collect_stats, void *stream, uint32_t *launch_id_out,
                   bool refuse_oversize);
+}
+
+// the wavefront schedule: a host-driven sequence of launches, synchronous (rtc_wavefront.inc)
+int launch_wavefront(const DScene &scene, const DRenderParams &params, double *d_rgb, const WfBuffers &b,
+                     unsigned *d_work, unsigned n_cu, void *stream, uint32_t *launch_id_out, uint32_t hsize,
+                     uint32_t *generations_out);
+namespace fastfp {
+int launch_wavefront(const DScene &scene, const DRenderParams &params, double *d_rgb, const WfBuffers &b,
+                     unsigned *d_work, unsigned n_cu, void *stream, uint32_t *launch_id_out, uint32_t hsize,
+                     uint32_t *generations_out);
 }
 
 // launch ids: unique per process (scenes on one GPU may share a work buffer), never 0

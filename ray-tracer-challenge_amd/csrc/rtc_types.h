@@ -273,6 +273,37 @@ struct DRenderParams {
     const uint32_t *tile_perm;
 };
 
+// ---- wavefront schedule (rtc_wavefront.inc): queue records ----
+struct WfRay {  // 64 B: what one intersection pass needs
+    double o[3], d[3];
+    double lim;     // closest hit: +inf; shadow: distance to the light sample; containers: t of the hit
+    int32_t prim;   // containers: the hit primitive; otherwise -1
+    uint32_t mode;  // MODE_CLOSEST / MODE_SHADOW / MODE_CONTAINER
+};
+struct WfHit {  // 32 B: what the pass found (per mode: see k_traverse)
+    double x0, x1, x2;
+    int32_t i0, i1;
+};
+struct WfCtx {  // 144 B: the path context an item carries from stage to stage
+    uint32_t pixel;     // index of the pixel in this launch's compact canvas
+    int32_t remaining;  // bounce budget of the ray (world.rs:93-106: only reflection spends it)
+    double w;           // what a colour found along this ray weighs in the pixel
+    // the hit being shaded (valid from the closest-hit stage to the hit's last light):
+    double point[3], eye[3], normal[3];
+    double kr;          // Schlick reflectance (1 unless reflective and transparent)
+    double surface[3];  // Material::lighting summed over the lights evaluated so far
+    int32_t h_prim, h_mat;
+    int32_t li;         // light in hand, and the area-light sample in hand
+    uint32_t su, sv, unshadowed;
+};
+static_assert(sizeof(WfRay) == 64 && sizeof(WfHit) == 32 && sizeof(WfCtx) == 144, "queue records are read as whole lines");
+#ifndef RTC_WF_MIN_WAVES
+#define RTC_WF_MIN_WAVES 4  // waves per SIMD the traversal kernel's register allocation leaves room for
+#endif
+#ifndef RTC_WF_CLAIM
+#define RTC_WF_CLAIM 64u    // items a wave claims from the queue per request
+#endif
+
 // device-side counters, one uint64 each (index constants)
 enum StatIdx {
     ST_PRIMARY = 0,

@@ -401,3 +401,36 @@ def test_large_canvas_download_is_exact_whole_and_tiled():
         assert np.all(part[others] == 0.0)  # rows of the other shares come back black (rtc_render clears the canvas)
     finally:
         scene.close()
+
+
+def test_wavefront_schedule_matches_oracle_and_megakernel():
+    # schedule = 3 (experimental): rays in device queues, one traversal kernel (the megakernel's pass code) and one
+    # shading kernel per kind of ray and generation.  Same arithmetic per stage, contributions added with f64 atomics.
+    import os
+    scenes = []
+    for name, w, h in (("cover", 96, 96), ("reflective_world", 120, 60), ("teapot", 64, 32)):
+        sc = rtc.parse_scene_file(os.path.join(sf.ROOT, "scenes", name + ".yaml"), w, h)
+        scenes.append((name, rtc.World(sc.objects, sc.lights), sc.camera))
+    scenes.append(("glass",) + _glass_scene(96, 64))
+    stripes = rtc.StripePattern(rtc.SolidPattern((1, 0.2, 0.2)), rtc.SolidPattern((0.2, 0.2, 1)), M.scaling(0.25, 1, 1))
+    area = rtc.AreaLight((-3, 6, -6), (2, 0, 0), 3, (0, 2, 0), 3, (1, 1, 1))
+    scenes.append(("patterns + area light + group",
+                   rtc.World([_floor(pattern=stripes, reflectivity=0.2),
+                              rtc.Group(transformation=M.translation(0, 1, 0), material=None, children=[rtc.Sphere(M.scaling(0.8, 0.8, 0.8), rtc.Material(transparency=0.7, refractive_index=1.4, reflectivity=0.3)),
+                                                                 rtc.Cube(M.scaling(0.4, 0.4, 0.4).translate(1.6, 0, 0))])],
+                             [area, rtc.PointLight((4, 5, -3), (0.4, 0.4, 0.4))]), _cam(80, 48)))
+    for label, world, cam in scenes:
+        scene = cam.compile(world, device=0)
+        try:
+            mega = scene.render(schedule=1)
+            wave = scene.render(schedule=3)
+            part = scene.render(schedule=3, tile_rows=8, tile_index=1, tile_count=3)
+            rows = scene.local_row_map(tile_rows=8, tile_index=1, tile_count=3)
+        finally:
+            scene.close()
+        ref = sf.to_oracle(world, cam).render()
+        rep = sf.compare(wave, ref)
+        print(f"[parity] wavefront {label}: {rep}")
+        assert rep["nan"] == 0 and rep["max_8bit"] <= 1 and rep["max_abs"] < 1e-9, (label, rep)
+        assert float(np.max(np.abs(wave - mega))) < 1e-12, label
+        assert float(np.max(np.abs(part[rows] - mega[rows]))) < 1e-12, label
