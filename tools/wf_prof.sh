@@ -11,5 +11,5 @@ db = glob.glob("gpurun_out/prof_%s/**/*.db" % sys.argv[1], recursive=True)[0]
 c = sqlite3.connect(db)
 for name, calls, total, avg, pct in c.execute("select * from top_kernels"):
     if "rocclr" in name: continue
-    print("  %-64s %6d launches %10.1f ms in all" % (name[:64], calls, total / 1e6))
+    print("  %-64s %6d launches %10.1f ms in all" % (name[:64], calls, total / 1e3))
 PY
