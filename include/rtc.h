@@ -228,7 +228,7 @@ int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_r
  * scene's launches: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO
  * counterpart in the reference.  Same arguments, same pixels.  The kernel's work buffer (tile counters, overflow flag,
  * mailboxes of the end-of-frame ray exchange) is a file-scope `static __device__` array of the library's code object
- * instead of the per-scene buffer that rtc_scene_commit allocated: RTC_STATIC_SCRATCH_BYTES (155 MB: per wave of the
+ * instead of the per-scene buffer that rtc_scene_commit allocated: RTC_STATIC_SCRATCH_BYTES (172 MB: per wave of the
  * persistent grid a mailbox and, per lane, the ring of waiting refracted rays, for RTC_STATIC_SCRATCH_WAVES waves) per
  * GPU, held until the process ends.  Limits: collect_stats is refused; frames beyond 2^26 8x8 tiles are refused (as by
  * every entry point); the persistent grid is capped at RTC_STATIC_SCRATCH_WAVES resident waves (MI355X: 3072).  Every
@@ -236,7 +236,7 @@ int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_r
  * them.  The call itself makes no hipMalloc / hipFree / allocating runtime call (a share of the frame whose tile order
  * has not been uploaded by an earlier rtc_render / rtc_render_device call is rendered in raster order). */
 #define RTC_STATIC_SCRATCH_WAVES 4096u
-#define RTC_STATIC_SCRATCH_BYTES (36864u + RTC_STATIC_SCRATCH_WAVES * 64u * (80u + 512u))
+#define RTC_STATIC_SCRATCH_BYTES (36864u + RTC_STATIC_SCRATCH_WAVES * 64u * (80u + 576u))
 int rtc_render_device_static(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream);
 /* Number of canvas rows owned by (tile_index, tile_count, tile_rows) and their canvas row numbers. */
 uint32_t rtc_local_rows(uint32_t vsize, uint32_t tile_rows, uint32_t tile_index, uint32_t tile_count);

@@ -772,12 +772,20 @@ enum ParkSlot {
     PK_POINT = 0,   // h_point  (3)
     PK_NORMAL = 3,  // h_normal (3)
     PK_EYE = 6,     // h_eye    (3)
-    PK_COLOR = 9,   // accumulated pixel colour (3)
-    PK_SURFACE = 12,  // sum of Material::lighting over the lights evaluated so far (3)
+    PK_SURFACE = 9,  // sum of Material::lighting over the lights evaluated so far (3)
+    PK_COUNT_SIDE = 12,  // (persistent grid: the three below live in the lane's line of the work buffer, RTC_SIDE_SLOT)
+    PK_COLOR = 12,  // accumulated pixel colour (3)
     PK_W = 15,
     PK_KR = 16,  // Schlick reflectance of the hit (1 unless the material is both reflective and transparent)
     PK_COUNT = 17
 };
+// The persistent grid keeps colour, weight and Schlick factor -- the five parked values that are touched least often -- in
+// a line of the work buffer: 12 LDS slots are 10 KB per wave with the traversal stack, which lets 16 waves share a CU
+// instead of 12, and the traversal is latency bound (profiles/r2_ab/r2_wf_grid.txt, r2_ab_occ.txt).  The register
+// allocation follows: 128 VGPRs, the state machine spills ~50 of them.
+#ifndef RTC_MIN_WAVES_PERSISTENT
+#define RTC_MIN_WAVES_PERSISTENT (RTC_SIDE_SLOT && RTC_RING_GLOBAL ? 4 : RTC_MIN_WAVES)
+#endif
 typedef __attribute__((address_space(3))) double lds_f64;  // an LDS pointer the compiler can not mistake for flat
 DEV void park3(lds_f64 *base, int slot, V3 v) {
     base[(slot + 0) * RTC_WAVE] = v.x;
@@ -891,12 +899,13 @@ DEV double lane_f64(double v, int src) {
 // tiles from device counters, refill free lanes pixel by pixel and, once the tiles have run out, pass waiting rays
 // to free lanes of the same wave and -- through per-wave mailboxes in `work` -- of other waves.
 template <bool STATS, bool GROUPS, bool PATTERNS, bool PERSISTENT, bool QNODES>
-__global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DRenderParams prm,
+__global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : RTC_MIN_WAVES) void k_render(DScene s, DRenderParams prm,
                                                                      double *__restrict__ out,
                                                                      unsigned long long *__restrict__ stats,
                                                                      unsigned *__restrict__ work) {
     __shared__ int bvh_stack[RTC_LDS_STACK * RTC_WAVE];
-    __shared__ double parked[PK_COUNT * RTC_WAVE];
+    constexpr bool SIDE = PERSISTENT && RTC_RING_GLOBAL && RTC_SIDE_SLOT;
+    __shared__ double parked[(SIDE ? PK_COUNT_SIDE : PK_COUNT) * RTC_WAVE];
 #if RTC_LDS_TOP
     // A/B only ("LDS staging"): the first RTC_LDS_TOP nodes of the breadth-first hierarchy -- its
     // top levels -- copied into LDS by every wave.  LDS is what bounds the occupancy (12.8 KB per wave x 12 waves of the
@@ -948,7 +957,30 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
     Pending pend_private[RTC_MAX_DEPTH_STACK];
     // (persistent grid: the ring lives in the work buffer, one 64-byte line per entry, [wave][lane][entry])
     Pending *const pend_global =
-        (Pending *)((char *)work + RTC_WORK_RING_OFFSET) + ((size_t)blockIdx.x * RTC_WAVE + threadIdx.x) * RTC_RING_SLOTS;
+        (Pending *)((char *)work + RTC_WORK_RING_OFFSET) + ((size_t)blockIdx.x * RTC_WAVE + threadIdx.x) * RTC_LANE_LINES;
+    // the lane's side line behind its ring: colour[3], weight, Schlick factor (SIDE), else their LDS slots
+    double *const side = (double *)(pend_global + RTC_RING_SLOTS);
+    auto get_color = [&]() { return SIDE ? mk(side[0], side[1], side[2]) : unpark3(pk, PK_COLOR); };
+    auto set_color = [&](V3 v) {
+        if (SIDE)
+            side[0] = v.x, side[1] = v.y, side[2] = v.z;
+        else
+            park3(pk, PK_COLOR, v);
+    };
+    auto get_w = [&]() { return SIDE ? side[3] : (double)pk[PK_W * RTC_WAVE]; };
+    auto set_w = [&](double v) {
+        if (SIDE)
+            side[3] = v;
+        else
+            pk[PK_W * RTC_WAVE] = v;
+    };
+    auto get_kr = [&]() { return SIDE ? side[4] : (double)pk[PK_KR * RTC_WAVE]; };
+    auto set_kr = [&](double v) {
+        if (SIDE)
+            side[4] = v;
+        else
+            pk[PK_KR * RTC_WAVE] = v;
+    };
 #define pend_at(i) (*((PERSISTENT && RTC_RING_GLOBAL) ? &pend_global[i] : &pend_private[i]))
 #if RTC_RING_PAD
     // A/B only ("the ring's write traffic"): every push also stores a second, unused entry, i.e.
@@ -1018,8 +1050,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 const V3 pixel = xf_point(cam->inv, mk(wx, wy, -1.));
                 ray.o = xf_point(cam->inv, mk(0., 0., 0.));
                 ray.d = normalize(pixel - ray.o);
-                park3(pk, PK_COLOR, mk(0., 0., 0.));
-                pk[PK_W * RTC_WAVE] = 1.;
+                set_color(mk(0., 0., 0.));
+                set_w(1.);
                 mult = 1.;
                 remaining = (int)prm.depth;
                 sp = 0, pbase = 0;
@@ -1040,7 +1072,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         const unsigned tile = prm.tile_order ? n_tiles - 1u - (pix >> 6) : (pix >> 6), q = pix & 63u;
         const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
         const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
-        const V3 color = unpark3(pk, PK_COLOR);
+        const V3 color = get_color();
         double *px = out + ((size_t)l * s.hsize + x) * 3u;
         if (PERSISTENT && shared) {
             // one of several lanes that traced parts of this pixel's ray tree (the pixel was zeroed when the first
@@ -1057,8 +1089,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         shared = true;
         alive = true;
         ray.o = qo, ray.d = qd, remaining = qrem;
-        park3(pk, PK_COLOR, mk(0., 0., 0.));
-        pk[PK_W * RTC_WAVE] = qw;
+        set_color(mk(0., 0., 0.));
+        set_w(qw);
         if (STATS) mult = qmult;
         sp = 0, pbase = 0;
         rays = 1;
@@ -1354,7 +1386,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 park3(pk, PK_POINT, h_point);
                 park3(pk, PK_EYE, h_eye);
                 park3(pk, PK_NORMAL, n);
-                pk[PK_KR * RTC_WAVE] = 1.;
+                set_kr(1.);
                 CNT(ST_SHADED, 1);
                 if (remaining > 0 && m_transparency != 0.) {
                     // containers loop (intersection.rs:150-179) in streaming form: second pass over the same
@@ -1401,7 +1433,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                     kr = r;
                     kt = 1. - r;
                 }
-                pk[PK_KR * RTC_WAVE] = kr;  // reflected_color's share, used by shade_hit's tail below
+                set_kr(kr);  // reflected_color's share, used by shade_hit's tail below
                 const double n_ratio = n1 / n2;
                 const double cos_i = dot(h_eye, h_normal);
                 const double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
@@ -1412,7 +1444,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                         Pending &q = pend_at(RTC_PEND(sp));
                         q.o = unpark3(pk, PK_POINT) - h_normal * RTC_EPS;  // under_point
                         q.d = h_normal * (n_ratio * cos_i - cos_t) - h_eye * n_ratio;
-                        q.w = pk[PK_W * RTC_WAVE] * (nl * (m_transp * kt));
+                        q.w = get_w() * (nl * (m_transp * kt));
                         q.remaining = remaining;  // Q2: not decremented (world.rs:142)
 #if RTC_RING_PAD
                         {
@@ -1526,8 +1558,8 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         if (finish) {
             // World::shade_hit (world.rs:42-76).  The reference evaluates reflected_color/refracted_color inside
             // the per-light loop (Q3), i.e. adds them n_lights times: that factor goes into the child's weight.
-            const double w = pk[PK_W * RTC_WAVE];
-            park3(pk, PK_COLOR, unpark3(pk, PK_COLOR) + unpark3(pk, PK_SURFACE) * w);
+            const double w = get_w();
+            set_color(get_color() + unpark3(pk, PK_SURFACE) * w);
             next_ray = true;
             if (remaining > 0 && f_refl != 0.) {
                 // reflected_color, world.rs:93-106 (the refracted ray, if any, already waits in the ring)
@@ -1535,7 +1567,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 const V3 h_eye = unpark3(pk, PK_EYE);
                 ray.o = unpark3(pk, PK_POINT) + h_normal * RTC_EPS;  // over_point
                 ray.d = reflect(-h_eye, h_normal);
-                pk[PK_W * RTC_WAVE] = w * (nl * (f_refl * pk[PK_KR * RTC_WAVE]));
+                set_w(w * (nl * (f_refl * get_kr())));
                 remaining -= 1;
                 if (STATS) mult = mult * nl;
                 next_ray = false;
@@ -1554,7 +1586,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
                 sp--;
                 const Pending q = pend_at(RTC_PEND(sp));
                 ray.o = q.o, ray.d = q.d, remaining = q.remaining;
-                pk[PK_W * RTC_WAVE] = q.w;
+                set_w(q.w);
                 if (STATS) mult = pend_mult[RTC_PEND(sp)];
                 T.mode = MODE_CLOSEST;
                 T.lim = inf, T.prim = -1;
@@ -1566,7 +1598,7 @@ __global__ __launch_bounds__(RTC_WAVE, RTC_MIN_WAVES) void k_render(DScene s, DR
         if (rays > (int)prm.max_rays) {
             CNT(ST_OVERFLOW, 1);
             flag_overflow();
-            park3(pk, PK_COLOR, mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.));
+            set_color(mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.));
             alive = false;
         }
         SUB_END(ST_BOX);
