@@ -38,6 +38,9 @@ WORKLOADS = {
     "reflective_world_1080p": ("reflective_world", 1920, 1080),
     "ice_cream_1080p": ("ice_cream", 1920, 1080),
 }
+# oracle pixels per extra workload (seeded-random; ~2 s of oracle time each on 16 host threads)
+PARITY_PIXELS = {"cover_4k": 100_000, "cover_1080p": 100_000, "teapot_4k": 40_000, "reflective_world_1080p": 300_000,
+                 "ice_cream_1080p": 300_000, "stress_1080p": 32, "stress_8k": 32, "stress_4k": 32}
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop (FMA) x 2.4 GHz; strict mode cannot use FMA
 TILE_ROWS = 8
 
@@ -73,9 +76,9 @@ def main():
     ap.add_argument("--extra-stress", action="store_true", help="include the (slow) stress scene in --extra")
     ap.add_argument("--extra", action="store_true", help="(default at N=1) also time the reference sample scenes")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--fp-mode", default="strict", choices=["strict", "fast"],
-                    help="flavour of the TIMED frames (the headline is strict; the other flavour is reported beside it)")
-    ap.add_argument("--no-flavours", action="store_true", help="skip the comparison frame of the other fp flavour")
+    ap.add_argument("--no-flavours", action="store_true", help="(accepted and ignored: the contracted flavour is gone)")
+    ap.add_argument("--parity-pixels", type=int, default=0,
+                    help="oracle pixels per extra workload (0 = sized for ~2 s of oracle time each)")
     args = ap.parse_args()
 
     import numpy as np
@@ -115,9 +118,6 @@ def main():
     hsize, vsize = cam.hsize, cam.vsize
     tile = dict(tile_rows=TILE_ROWS, tile_index=rank, tile_count=world_size) if distributed else {}
     ropts = dict(tile)
-    fp_mode = 1 if args.fp_mode == "fast" else 0
-    if fp_mode:
-        ropts["fp_mode"] = fp_mode
     if args.schedule:
         ropts["schedule"] = args.schedule
     if args.use_bvh:
@@ -253,7 +253,7 @@ def main():
                 args.workload, WORKLOADS[args.workload][0], hsize, vsize, (hsize - 1) * (vsize - 1)),
             "sharding": "interleaved %d-row tiles over %d rank(s); RCCL gather to rank 0" % (TILE_ROWS, world_size)
             if distributed else "single GPU, whole frame in one launch",
-            "fp_mode": "fast (FMA contraction, shared reciprocals)" if fp_mode else "strict (no FMA contraction)",
+            "fp_mode": "strict (no FMA contraction: the reference's arithmetic; there is no other flavour)",
         },
         "rays_per_frame": {
             "primary": frame["primary_rays"], "shadow": frame["shadow_rays"], "secondary": frame["secondary_rays"],
@@ -284,29 +284,10 @@ def main():
         },
     }
 
-    if not args.no_flavours and not distributed:
-        # headline frame in the other flavour (one untimed + two timed launches) and its distance from the timed one
-        other = 0 if fp_mode else 1
-        kw = dict(ropts, fp_mode=other)
-        timed_canvas = buf.cpu().numpy()
-        scene.render_device(buf.data_ptr(), stream.cuda_stream, **kw)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(stream)
-        for _ in range(2):
-            scene.render_device(buf.data_ptr(), stream.cuda_stream, **kw)
-        b.record(stream)
-        torch.cuda.synchronize(dev)
-        scene.check()
-        o_ms = a.elapsed_time(b) / 2
-        rep = compare(buf.cpu().numpy(), timed_canvas)
-        out["other_flavour"] = {"fp_mode": "strict" if fp_mode else "fast", "frame_ms": o_ms,
-                                "roofline_frac": local_flops / (o_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                "max_abs_vs_timed": rep["max_abs"], "max_8bit_vs_timed": rep["max_8bit"],
-                                "channels_differing_8bit": rep["mismatched_channels"]}
-        # leave the timed flavour's frame in `buf` for the parity check below
-        scene.render_device(buf.data_ptr(), stream.cuda_stream, **ropts)
-        torch.cuda.synchronize(dev)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    threads = min(os.cpu_count() or 1, 16)
     if not args.no_extra and not distributed:
+        import scene_feed as sf
         extra = {}
         for wl in WORKLOADS:
             if wl == args.workload or (wl.startswith("stress") and not args.extra_stress):
@@ -341,57 +322,64 @@ def main():
             t1 = time.perf_counter()
             s2.render(out=host, **kw2)
             extra[wl]["render_call_ms"] = (time.perf_counter() - t1) * 1e3
-            if not args.no_flavours:
-                # the other fp flavour on the same frame: time and distance from the strict canvas
-                a.record(stream)
-                for _ in range(reps):
-                    s2.render_device(b2.data_ptr(), stream.cuda_stream, fp_mode=1, **kw2)
-                b.record(stream)
-                torch.cuda.synchronize(dev)
-                fast_ms = a.elapsed_time(b) / reps
-                fast = b2.cpu().numpy()
-                rep = compare(fast, host)
-                extra[wl]["fast_flavour"] = {"frame_ms": fast_ms, "max_abs_vs_strict": rep["max_abs"],
-                                             "max_8bit_vs_strict": rep["max_8bit"],
-                                             "channels_differing_8bit": rep["mismatched_channels"],
-                                             "roofline_frac": st2["algorithmic_flops"] / fast_ms / 1e9 / FP64_VALU_PEAK_TFLOPS}
+            # parity of the frame just timed: seeded-random pixels against the oracle (brute force -- a sample sized for
+            # a couple of seconds of CPU time; `host` holds the canvas of the second rtc_render call above)
+            ow2 = sf.to_oracle(w2, c2)
+            rng = np.random.default_rng(0xBE7C4 + c2.hsize)
+            n_pix = args.parity_pixels or PARITY_PIXELS.get(wl, 20_000)
+            xy = np.stack([rng.integers(0, c2.hsize - 1, n_pix), rng.integers(0, c2.vsize - 1, n_pix)], axis=1)
+            ref = ow2.render_pixels(xy, threads=threads)
+            dev_canvas = b2.cpu().numpy()
+            rep = compare(dev_canvas[xy[:, 1], xy[:, 0]], ref)
+            extra[wl]["parity"] = {"against": "C oracle, %d seeded-random pixels of the timed frame" % n_pix,
+                                   "pixels": n_pix, "max_abs": rep["max_abs"], "mismatched_8bit": rep["mismatched_channels"],
+                                   "pixels_over_1_of_255": rep["pixels_over_1"], "nan": rep["nan"],
+                                   "oracle_seconds": ow2.last_stats["seconds"],
+                                   "render_call_equals_device_frame": bool(np.array_equal(host, dev_canvas)),
+                                   "within_tolerance": bool(rep["pixels_over_1"] == 0 and rep["nan"] == 0)}
             s2.close()
         out["extra_workloads"] = extra
 
     if not args.no_cpu_baseline and not distributed:
         # The reference is Rust and can not be built here (no toolchain): the baseline is the C oracle (brute force,
-        # no BVH, the reference's recursion), rows over threads like the reference's rayon loop, on a time-bounded
-        # sample of the SAME frame (pixels on a regular grid).
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        # no BVH, the reference's recursion), pixels over threads like the reference's rayon loop over rows, on a
+        # time-bounded sample of the SAME frame: batches of seeded-random pixels until ~10 s of CPU time are spent.
+        # The same pixels are the parity check of the timed frame; the stress scene adds pixels picked inside its
+        # nearest glass spheres (the deep ray trees the end-of-frame exchange splits) to the check, not to the baseline.
         import scene_feed as sf
-        threads = min(os.cpu_count() or 1, 16)
         gpu_canvas = buf.cpu().numpy()  # the frame of the timed region
-        max_abs, mism8, over1, npix, nan = 0.0, 0, 0, 0, 0
         ow = sf.to_oracle(world, cam)
-        heavy = args.workload == "stress_4k"  # ~3 ms of CPU work per ray (106k primitives per ray)
-        rstep, cstep = (135, 480) if heavy else (48, 48)
+        heavy = WORKLOADS[args.workload][0] == "stress"  # ~3 ms of CPU work per ray (106k primitives per ray)
+        batch = 32 if heavy else 20_000
         if args.cpu_sample_stride > 0:
-            rstep = cstep = args.cpu_sample_stride
-        cpu_rays, cpu_secs, cpu_pixels, offset = 0, 0.0, 0, 0
-        while cpu_secs < 10.0 and offset < rstep:
-            ref = ow.render(threads=threads, subset=(offset, vsize, rstep, cstep))
-            cs = ow.last_stats
+            batch = args.cpu_sample_stride
+        rng = np.random.default_rng(0xBA5E11)
+        max_abs, mism8, over1, npix, nan = 0.0, 0, 0, 0, 0
+        cpu_rays, cpu_secs, cpu_pixels = 0, 0.0, 0
+
+        def check(xy):
+            nonlocal max_abs, mism8, over1, npix, nan
+            ref = ow.render_pixels(xy, threads=threads)
             # north_star: "a reported per-pixel max-abs float delta" -- the oracle's pixels against the GPU frame
-            rows, cols = slice(offset, vsize - 1, rstep), slice(0, hsize - 1, cstep)
-            rep = compare(gpu_canvas[rows, cols], ref[rows, cols])
+            rep = compare(gpu_canvas[xy[:, 1], xy[:, 0]], ref)
             max_abs, nan = max(max_abs, rep["max_abs"]), nan + rep["nan"]
             mism8, over1 = mism8 + rep["mismatched_channels"], over1 + rep["pixels_over_1"]
-            npix += ref[rows, cols].shape[0] * ref[rows, cols].shape[1]
+            npix += len(xy)
+            return ow.last_stats
+
+        while cpu_secs < 10.0 and cpu_pixels < (hsize - 1) * (vsize - 1):
+            xy = np.stack([rng.integers(0, hsize - 1, batch), rng.integers(0, vsize - 1, batch)], axis=1)
+            cs = check(xy)
             cpu_rays += cs["primary"] + cs["shadow"] + cs["secondary"]
             cpu_pixels += cs["primary"]
             cpu_secs += cs["seconds"]
-            # the next batch takes the rows in between; cheap scenes get denser batches
-            offset += max(1, rstep // 8) if heavy else 1
-            if not heavy and cpu_secs < 1.0 and rstep > 2 and offset == 1:
-                rstep, cstep, offset = max(1, rstep // 4), max(1, cstep // 4), 0
-                cpu_rays, cpu_secs, cpu_pixels = 0, 0.0, 0
-                max_abs, mism8, over1, npix, nan = 0.0, 0, 0, 0, 0
-        out["parity"] = {"against": "C oracle (oracle/rtc_oracle.c), same frame, pixels on a regular grid",
+            if not heavy and cs["seconds"] < 1.0:
+                batch *= 4
+        glass = sf.glass_pixels(world, cam, 12) if heavy else np.zeros((0, 2), dtype=np.int64)
+        if len(glass):
+            check(glass)
+        out["parity"] = {"against": "C oracle (oracle/rtc_oracle.c), pixels of the timed frame: %d seeded-random%s" % (
+                             cpu_pixels, " + %d at the centres of the nearest glass spheres" % len(glass) if len(glass) else ""),
                          "pixels": npix, "max_abs": max_abs, "mismatched_8bit": mism8, "pixels_over_1_of_255": over1,
                          "nan": nan, "within_tolerance": bool(over1 == 0 and nan == 0)}
         out["cpu_baseline"] = {
@@ -399,8 +387,9 @@ def main():
             "unit": "Mrays/s",
             "cores": threads,
             "kind": "port",
-            "sample": "C oracle (brute force, no BVH, reference recursion), %d pixels on a regular grid of the same "
-                      "%dx%d frame: %d rays in %.1f s" % (cpu_pixels, hsize, vsize, cpu_rays, cpu_secs),
+            "sample": "SAMPLED: C oracle (brute force, no BVH, reference recursion, reference-equivalent ray count) on %d "
+                      "seeded-random pixels of the same %dx%d frame: %d rays in %.1f s; not a whole-frame time" % (
+                          cpu_pixels, hsize, vsize, cpu_rays, cpu_secs),
         }
     print(json.dumps(out))
     if distributed:

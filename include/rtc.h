@@ -95,12 +95,11 @@ typedef struct rtc_render_opts {
                             call reports RTC_ERR_OVERFLOW.  0 = default (65536).  With the ray exchange (schedule 2,
                             exchange != 1) every lane that takes over part of a pixel's ray tree counts from 1 again, so
                             the cap bounds the work of one lane, not the size of the tree */
-    uint32_t fp_mode;    /* 0 = strict: no FMA contraction, IEEE division and sqrt, the reference's operation order (the
-                            parity flavour).  1 = fast: contraction and shared reciprocals allowed; not bit-equal: every
-                            colour is within ~1e-10 of strict as long as each ray hits the same primitive in both
-                            flavours; a ray that grazes an edge may not, and mirrors / glass carry that difference on
-                            (measured: 0 channels off by more than 1/255 on the scenes without glass, a few pixels per
-                            frame on those with it -- DESIGN.md section 5) */
+    uint32_t fp_mode;    /* must be 0: strict -- no FMA contraction, IEEE division and sqrt, the reference's operation
+                            order.  (Rounds 1-2 offered 1 = contraction and shared reciprocals: 2 % faster, but a ray that
+                            grazes an edge landed on its other side and glass / mirrors carried that on, up to 95/255 in
+                            single pixels; it did not meet the parity bar and was removed.  Any other value is refused
+                            with RTC_ERR_INVALID.) */
     uint32_t reserved[6];
 } rtc_render_opts;
 

@@ -1340,6 +1340,76 @@ int orc_render_subset(orc_world *w, int nthreads, uint32_t row_begin, uint32_t r
     return ORC_OK;
 }
 
+/* The same loop body (camera.rs:78-84: ray_for_pixel, color_at(ray, 5)) for an explicit list of pixels: test
+ * infrastructure for parity checks of large frames on seeded-random or hand-picked pixels.  xy holds n (x, y) pairs;
+ * pixels of the last row / column (never rendered, Q1) come back black.  rgb_out: 3 doubles per listed pixel. */
+typedef struct {
+    orc_world *w;
+    const uint32_t *xy;
+    double *out;
+    size_t n;
+    volatile size_t *next;
+    pthread_mutex_t *mu;
+    counters_t counters;
+} pjob_t;
+
+static void *pixels_worker(void *arg) {
+    pjob_t *j = (pjob_t *)arg;
+    orc_world *w = j->w;
+    tl_counters = &j->counters;
+    for (;;) {
+        pthread_mutex_lock(j->mu);
+        size_t i = *j->next;
+        *j->next = i + 1;
+        pthread_mutex_unlock(j->mu);
+        if (i >= j->n) break;
+        const uint32_t x = j->xy[2 * i], y = j->xy[2 * i + 1];
+        double *px = j->out + 3 * i;
+        px[0] = px[1] = px[2] = 0.;
+        if (x + 1 >= w->hsize || y + 1 >= w->vsize) continue; /* camera.rs:72,78 (Q1) */
+        ray_t ray = camera_ray_for_pixel(w, x, y);
+        j->counters.primary++;
+        v3 c = world_color_at(w, &ray, w->depth_override ? w->depth_override - 1 : 5); /* camera.rs:80 */
+        px[0] = c.x, px[1] = c.y, px[2] = c.z;
+    }
+    tl_counters = NULL;
+    return NULL;
+}
+
+int orc_render_pixels(orc_world *w, int nthreads, size_t n, const uint32_t *xy, double *rgb_out, orc_stats *stats) {
+    if (!w->has_camera || w->hsize == 0 || w->vsize == 0 || (n && (!xy || !rgb_out))) return ORC_ERR_INVALID;
+    if (!world_check_invertible(w)) return ORC_ERR_NON_INVERTIBLE;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    volatile size_t next = 0;
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_t th[256];
+    pjob_t jobs[256];
+    for (int i = 0; i < nthreads; i++) {
+        memset(&jobs[i], 0, sizeof(pjob_t));
+        jobs[i].w = w, jobs[i].xy = xy, jobs[i].out = rgb_out, jobs[i].n = n;
+        jobs[i].next = &next, jobs[i].mu = &mu;
+        pthread_create(&th[i], NULL, pixels_worker, &jobs[i]);
+    }
+    counters_t total = {0, 0, 0};
+    for (int i = 0; i < nthreads; i++) {
+        pthread_join(th[i], NULL);
+        total.primary += jobs[i].counters.primary;
+        total.shadow += jobs[i].counters.shadow;
+        total.secondary += jobs[i].counters.secondary;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (stats) {
+        stats->primary_rays = total.primary;
+        stats->shadow_rays = total.shadow;
+        stats->secondary_rays = total.secondary;
+        stats->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    }
+    return ORC_OK;
+}
+
 /* camera.rs:64-93 */
 int orc_render(orc_world *w, int nthreads, double *rgb_out, orc_stats *stats) {
     return orc_render_subset(w, nthreads, 0, w->vsize, 1, 1, rgb_out, stats);

@@ -131,6 +131,9 @@ int orc_shape_includes(orc_world *w, int shape, int object);
 int orc_render(orc_world *w, int nthreads, double *rgb_out, orc_stats *stats);
 int orc_render_subset(orc_world *w, int nthreads, uint32_t row_begin, uint32_t row_end, uint32_t row_step,
                       uint32_t col_step, double *rgb_out, orc_stats *stats);
+/* The loop body of Camera::render (camera.rs:78-84) for an explicit list of n pixels, xy = n (x, y) pairs;
+ * rgb_out = 3 doubles per listed pixel (black for the never-rendered last row / column). */
+int orc_render_pixels(orc_world *w, int nthreads, size_t n, const uint32_t *xy, double *rgb_out, orc_stats *stats);
 
 /* ---- unit-level entry points used by the known-answer tests ---- */
 int orc_camera_params(orc_world *w, double out_hw_hh_ps[3]);

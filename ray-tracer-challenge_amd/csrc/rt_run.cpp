@@ -1,5 +1,5 @@
 // rt_run -- the reference's CLI (rt_run/src/main.rs:10-44) on top of include/rtc.h:
-//   rt_run <scene.yaml> [--width W --height H] [--device D] [--gpus N] [--depth N] [--strict-fp | --fast-fp]
+//   rt_run <scene.yaml> [--width W --height H] [--device D] [--gpus N] [--depth N]
 // reads the YAML scene, renders it on one MI355X (or, with --gpus N, on devices D .. D+N-1 of this node: interleaved
 // 8-row tiles, canvas assembled on device D) and writes "<stem>.ppm" into the current directory, where
 // <stem> is the text before the first '.' of the path, after its last '/' (main.rs:32-39).
@@ -19,7 +19,7 @@ static int die(const char *what) {
 
 int main(int argc, char **argv) {
     const char *path = nullptr;
-    uint32_t width = 0, height = 0, depth = 5, fp_mode = 0;
+    uint32_t width = 0, height = 0, depth = 5;
     int device = 0, gpus = 1;
     for (int i = 1; i < argc; i++) {
         auto next = [&](const char *flag) -> const char * {
@@ -34,8 +34,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--device")) device = atoi(next("--device"));
         else if (!strcmp(argv[i], "--depth")) depth = (uint32_t)atoi(next("--depth"));
         else if (!strcmp(argv[i], "--gpus")) gpus = atoi(next("--gpus"));
-        else if (!strcmp(argv[i], "--strict-fp")) fp_mode = 0;
-        else if (!strcmp(argv[i], "--fast-fp")) fp_mode = 1;
+        else if (!strcmp(argv[i], "--strict-fp")) {}  // (the only arithmetic there is: the reference's, uncontracted)
         else if (!path) path = argv[i];
     }
     if (!path) {
@@ -58,7 +57,6 @@ int main(int argc, char **argv) {
     rtc_render_opts opts;
     rtc_render_opts_default(&opts);
     opts.depth = depth;
-    opts.fp_mode = fp_mode;
     rtc_stats st;
     const auto t0 = std::chrono::steady_clock::now();
     if (rtc_render(scene, &opts, rgb.data(), &st) != RTC_OK) return die("Should be able to render the scene");
@@ -82,7 +80,7 @@ int main(int argc, char **argv) {
     }
     fclose(f);
     printf("Wrote output to %s\n", out.c_str());
-    fprintf(stderr, "rt_run: %ux%u on %d GPU(s), %s fp, kernel %.3f ms, render call %.1f ms\n", hsize, vsize, gpus,
-            fp_mode ? "fast" : "strict", st.kernel_ms, ms);
+    fprintf(stderr, "rt_run: %ux%u on %d GPU(s), kernel %.3f ms, render call %.1f ms\n", hsize, vsize, gpus,
+            st.kernel_ms, ms);
     return 0;
 }

@@ -328,8 +328,9 @@ static int resolve_params(Scene &s, const rtc_render_opts *opts_in, DRenderParam
         set_error("depth %u exceeds the per-lane stack of waiting refracted rays (8)", o.depth);
         return RTC_ERR_INVALID;
     }
-    if (o.fp_mode > 1) {
-        set_error("fp_mode %u: 0 = strict, 1 = fast", o.fp_mode);
+    if (o.fp_mode != 0) {
+        set_error("fp_mode %u: only 0 (strict: the reference's arithmetic) exists; the contracted flavour of rounds 1-2 "
+                  "did not meet the 1/255 bar behind glass and was removed", o.fp_mode);
         return RTC_ERR_INVALID;
     }
     if (o.schedule > 3) {
@@ -351,7 +352,6 @@ static int resolve_params(Scene &s, const rtc_render_opts *opts_in, DRenderParam
     p.persistent = (o.schedule == 2) ? 1u : (o.schedule == 1) ? 0u : (s.n_transparent_prims > 64 ? 1u : 0u);
     p.share = (o.exchange == 1) ? 0u : 1u;
     p.max_rays = o.max_rays_per_pixel;
-    p.fast = o.fp_mode;
     p.tiles_x = (s.hsize + 7u) / 8u;
     p.tiles_y = (p.local_rows + 7u) / 8u;
     // a lane's pixel is tile * 64 + position in 32 bits
@@ -448,7 +448,7 @@ static int launch_on(Scene &s, DeviceReplica &r, const DRenderParams &p, const r
         int rc = ensure_wavefront(r, (size_t)p.local_rows * s.hsize);
         if (rc) return rc;
         r.last_work = work;
-        return (p.fast ? fastfp::launch_wavefront : launch_wavefront)(r.dscene, p, d_rgb, r.wf, work, r.n_cu, st,
+        return launch_wavefront(r.dscene, p, d_rgb, r.wf, work, r.n_cu, st,
                                                                       &r.last_launch_id, s.hsize, &r.wf_generations);
     }
     if (o.collect_stats) {
@@ -497,7 +497,7 @@ static int launch_on(Scene &s, DeviceReplica &r, const DRenderParams &p, const r
             pp.tile_perm = r.d_share_perm;
         }
     }
-    return (p.fast ? fastfp::launch_render : launch_render)(r.dscene, pp, d_rgb, r.d_stats, work, r.n_cu,
+    return launch_render(r.dscene, pp, d_rgb, r.d_stats, work, r.n_cu,
                                                             o.collect_stats != 0, st, &r.last_launch_id, refuse_oversize);
 }
 

@@ -29,18 +29,11 @@
 #include "rtc_scene.h"
 #include "rtc_types.h"
 
-// The file is compiled twice (Makefile): strict (-ffp-contract=off, rtc::launch_render: the parity flavour) and fast
-// (-ffp-contract=fast -DRTC_FAST, rtc::fastfp::launch_render: FMA contraction and shared reciprocals allowed).
-#ifdef RTC_FAST
-#define RTC_FLAVOUR_BEGIN namespace fastfp {
-#define RTC_FLAVOUR_END }
-#else
-#define RTC_FLAVOUR_BEGIN
-#define RTC_FLAVOUR_END
-#endif
+// Compiled with -ffp-contract=off (Makefile): the reference's Rust arithmetic is never contracted to FMA.  (Rounds 1-2
+// also built a `fast` flavour with contraction and shared reciprocals: 2 % faster, and pixels behind glass or mirrors
+// differed by up to 95/255 -- a grazing ray that lands on the other side of an edge -- so it was removed in round 3.)
 
 namespace rtc {
-RTC_FLAVOUR_BEGIN
 
 #define RTC_EPS 1e-5  // lib.rs:24
 #define RTC_WAVE 64
@@ -68,6 +61,9 @@ RTC_FLAVOUR_BEGIN
 #endif
 #ifndef RTC_LEAF_DEN
 #define RTC_LEAF_DEN 3  // quantised-node scenes; 64 = primitive tests never wait
+#endif
+#ifndef RTC_KILL_DEAD
+#define RTC_KILL_DEAD 1  // end the live ranges of the traversal's per-pass state across the state machine (see there)
 #endif
 #ifndef RTC_MIN_WAVES
 #define RTC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for
@@ -100,21 +96,11 @@ DEV V3 cross(V3 a, V3 b) {                                               // tupl
 DEV double magnitude(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // tuple.rs:96-99
 DEV V3 normalize(V3 a) {  // tuple.rs:101-108: three divisions
     const double m = magnitude(a);
-#ifdef RTC_FAST
-    const double r = 1. / m;  // fast flavour: one division shared by the three components
-    return mk(a.x * r, a.y * r, a.z * r);
-#else
     return mk(a.x / m, a.y / m, a.z / m);
-#endif
 }
 // the two roots (-b -+ sq) / (2a) of the quadrics (shape.rs:231-234, 917-918, 1238-1239)
 DEV void quadric_roots(double a, double b, double sq, double &t0, double &t1) {
-#ifdef RTC_FAST
-    const double r = 1. / (2. * a);  // fast flavour: one division for both roots
-    t0 = (-b - sq) * r, t1 = (-b + sq) * r;
-#else
     t0 = (-b - sq) / (2. * a), t1 = (-b + sq) / (2. * a);
-#endif
 }
 DEV V3 reflect(V3 v, V3 n) {  // tuple.rs:122-124: self - (normal * 2.) * self.dot(normal)
     const double d = dot(v, n);
@@ -1603,6 +1589,18 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         }
         SUB_END(ST_BOX);
         if (PERSISTENT && !alive) write_pixel();  // the lane is free for the next pixel
+#if RTC_KILL_DEAD
+        // A lane that went through the state machine is BETWEEN passes: the traversal's own state (cursor, stack pointer,
+        // node in hand, the f32 form of the ray) and the fold's scratch values are dead for it -- the next pass sets them
+        // before it reads them.  The compiler cannot see that (the reads sit behind `in_pass`), so it is told here: an
+        // empty asm "defines" them anew, which ends their old live ranges at their last use above instead of carrying
+        // them through the whole state machine.  (Per-lane liveness is what counts for VGPRs: the lanes that are inside a
+        // pass are masked off here and keep their values.)
+        asm volatile("" : "=v"(pos), "=v"(end), "=v"(sb), "=v"(cur));
+        asm volatile("" : "=v"(slab_ray.ax), "=v"(slab_ray.ay), "=v"(slab_ray.az));
+        asm volatile("" : "=v"(slab_ray.bx), "=v"(slab_ray.by), "=v"(slab_ray.bz));
+        asm volatile("" : "=v"(T.last), "=v"(T.a), "=v"(T.b), "=v"(T.c_best_prim), "=v"(T.c_hit_open));
+#endif
         }  // if (alive)
         STAGE_END(ST_CYC_SHADE);
     }
@@ -1760,5 +1758,4 @@ int launch_render(const DScene &scene, const DRenderParams &params_in, double *d
 
 #include "rtc_wavefront.inc"
 
-RTC_FLAVOUR_END
 }  // namespace rtc

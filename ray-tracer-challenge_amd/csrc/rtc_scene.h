@@ -161,21 +161,10 @@ int launch_render(const DScene &scene, const DRenderParams &params, double *d_rg
                   unsigned *d_work, unsigned n_cu, bool collect_stats, void *stream, uint32_t *launch_id_out,
                   bool refuse_oversize);
 
-namespace fastfp {  // the same kernels compiled with FMA contraction (rtc_render_opts.fp_mode = 1)
-int launch_render(const DScene &scene, const DRenderParams &params, double *d_rgb, uint64_t *d_stats,
-                  unsigned *d_work, unsigned n_cu, bool collect_stats, void *stream, uint32_t *launch_id_out,
-                  bool refuse_oversize);
-}
-
 // the wavefront schedule: a host-driven sequence of launches, synchronous (rtc_wavefront.inc)
 int launch_wavefront(const DScene &scene, const DRenderParams &params, double *d_rgb, const WfBuffers &b,
                      unsigned *d_work, unsigned n_cu, void *stream, uint32_t *launch_id_out, uint32_t hsize,
                      uint32_t *generations_out);
-namespace fastfp {
-int launch_wavefront(const DScene &scene, const DRenderParams &params, double *d_rgb, const WfBuffers &b,
-                     unsigned *d_work, unsigned n_cu, void *stream, uint32_t *launch_id_out, uint32_t hsize,
-                     uint32_t *generations_out);
-}
 
 // launch ids: unique per process (scenes on one GPU may share a work buffer), never 0
 uint32_t next_launch_id();

@@ -271,7 +271,7 @@ struct DRenderParams {
     uint32_t leaf_den;          // primitive tests run when at least 1/leaf_den of the traversing lanes wait at a leaf
     uint32_t launch_id;         // process-wide unique, never 0: what an overflowing lane stores into work[RTC_WORK_FLAG]
     uint32_t max_rays;          // rays one lane may trace for one pixel (or adopted subtree) before it gives up
-    uint32_t fast;              // rtc_render_opts.fp_mode: 1 selects the kernels compiled with FMA contraction
+    uint32_t pad1;
     uint32_t refuse_oversize;   // host only: 1 = a grid beyond RTC_MAX_WAVES with the exchange on is an error (2 = it was)
     uint32_t pad0;
     // static schedule, whole frame: workgroup b renders tile tile_perm[b] -- the tiles that show transparent or reflective

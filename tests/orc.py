@@ -90,6 +90,7 @@ def lib():
     L.orc_render.argtypes = [C.c_void_p, C.c_int, PD, C.POINTER(Stats)]
     L.orc_render_subset.argtypes = [
         C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, PD, C.POINTER(Stats)]
+    L.orc_render_pixels.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_uint32), PD, C.POINTER(Stats)]
     L.orc_camera_params.argtypes = [C.c_void_p, PD]
     L.orc_ray_for_pixel.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, PD, PD]
     L.orc_intersect.argtypes = [C.c_void_p, C.c_int, PD, PD, C.c_int, PD, PI32, PD, PD]
@@ -332,6 +333,24 @@ class World:
         else:
             rb, re, rs, cs = subset
             rc = self.L.orc_render_subset(self.h, threads, rb, re, rs, cs, out.ctypes.data_as(PD), C.byref(st))
+        if rc == ERR_NON_INVERTIBLE:
+            raise ValueError("NonInvertibleMatrix")
+        assert rc == OK, rc
+        self.last_stats = dict(primary=st.primary_rays, shadow=st.shadow_rays, secondary=st.secondary_rays,
+                               seconds=st.seconds)
+        return out
+
+    def render_pixels(self, xy, threads=None, depth=None):
+        """colours of an explicit list of pixels [(x, y), ...] -> (n, 3) array (camera.rs:78-84 per pixel)"""
+        threads = threads or min(os.cpu_count() or 1, 16)
+        self.L.orc_world_set_depth.argtypes = [C.c_void_p, C.c_int]
+        self.L.orc_world_set_depth.restype = None
+        self.L.orc_world_set_depth(self.h, 5 if depth is None else depth)
+        xy = np.ascontiguousarray(np.asarray(xy, dtype=np.uint32).reshape(-1, 2))
+        out = np.zeros((len(xy), 3), dtype=np.float64)
+        st = Stats()
+        rc = self.L.orc_render_pixels(self.h, threads, len(xy), xy.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      out.ctypes.data_as(PD), C.byref(st))
         if rc == ERR_NON_INVERTIBLE:
             raise ValueError("NonInvertibleMatrix")
         assert rc == OK, rc

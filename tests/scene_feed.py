@@ -106,3 +106,50 @@ def compare(gpu, ref):
     return dict(max_abs=float(np.nanmax(d)) if d.size else 0.0, nan=int(np.isnan(d).sum()),
                 max_8bit=int(d8.max()) if d8.size else 0, mismatched_channels=int((d8 > 0).sum()),
                 pixels_over_1=int((d8.max(axis=-1) > 1).sum()) if d8.size else 0)
+
+
+def project(camera, points):
+    """pixel (x, y) that a world-space point falls into (the inverse of Camera::ray_for_pixel, camera.rs:41-59), or
+    (-1, -1) for points behind the camera; test-side helper for picking pixels that show a given object"""
+    import math
+    hs, vs = camera.hsize, camera.vsize
+    half_view = math.tan(camera.field_of_view / 2.0)
+    aspect = hs / vs
+    hw, hh = (half_view, half_view / aspect) if aspect >= 1.0 else (half_view * aspect, half_view)
+    ps = hw * 2.0 / hs
+    m = np.asarray(camera.transformation.m, dtype=np.float64).reshape(4, 4)
+    pts = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    pc = pts @ m[:3, :3].T + m[:3, 3]
+    out = np.full((len(pts), 2), -1, dtype=np.int64)
+    ok = pc[:, 2] < -1e-9
+    wx, wy = pc[ok, 0] / -pc[ok, 2], pc[ok, 1] / -pc[ok, 2]
+    out[ok, 0] = np.floor((hw - wx) / ps).astype(np.int64)
+    out[ok, 1] = np.floor((hh - wy) / ps).astype(np.int64)
+    return out
+
+
+def glass_pixels(world, camera, count, nearest_of=4000):
+    """`count` pixels at the projected centres of transparent spheres, nearest to the camera first, one per sphere and
+    pixel, inside the rendered part of the canvas: the pixels whose ray trees are the deepest (refraction keeps the
+    bounce budget, world.rs:142) -- the ones the persistent schedule's end-of-frame exchange splits between lanes"""
+    m = np.asarray(camera.transformation.m, dtype=np.float64).reshape(4, 4)
+    cen = []
+    for o in world.objects:
+        if isinstance(o, rtc.Shape) and o.kind == rtc._native.SPHERE and o.material is not None and o.material.transparency > 0:
+            t = np.asarray(o.transformation.m, dtype=np.float64).reshape(4, 4)
+            cen.append(t[:3, 3])
+    if not cen:
+        return np.zeros((0, 2), dtype=np.int64)
+    cen = np.asarray(cen)
+    depth = -(cen @ m[2, :3] + m[2, 3])
+    order = np.argsort(depth)
+    order = order[depth[order] > 0][:nearest_of]
+    px = project(camera, cen[order])
+    seen, out = set(), []
+    for x, y in px:
+        if 0 <= x < camera.hsize - 1 and 0 <= y < camera.vsize - 1 and (x, y) not in seen:
+            seen.add((x, y))
+            out.append((x, y))
+            if len(out) == count:
+                break
+    return np.asarray(out, dtype=np.int64).reshape(-1, 2)

@@ -197,26 +197,15 @@ def test_stress_scene_headline_frame_depth5_matches_oracle():
     assert not np.isnan(gpu).any()
 
 
-@pytest.mark.parametrize("name,w,h", [("cover", 160, 160), ("reflective_world", 200, 100), ("teapot", 96, 48),
-                                      ("stress", 128, 72)])
-def test_fast_flavour_stays_within_one_of_255(name, w, h):
-    # rtc_render_opts.fp_mode = 1: FMA contraction and shared reciprocals (hard part 1).  Not
-    # bit-equal to the reference's arithmetic by design; the bar is BASELINE.json's 1/255 per 8-bit channel against the
-    # oracle, and the number of channels that differ at all is reported.
-    if name == "stress":
-        world, cam = rtc.stress_scene.build(1500, w, h, with_teapot=False)
-    else:
-        world, cam = sf.load(name, w, h)
+def test_contracted_flavour_is_refused():
+    # rounds 1-2 offered fp_mode = 1 (FMA contraction, shared reciprocals); it missed the 1/255 bar behind glass and
+    # was removed: the only arithmetic is the reference's, and any other fp_mode is an argument error
+    world, cam = sf.load("reflective_world", 40, 20)
     scene = cam.compile(world, device=0)
     try:
-        strict = scene.render()
-        fast = scene.render(fp_mode=1)
+        with pytest.raises(Exception) as e:
+            scene.render(fp_mode=1)
+        assert "fp_mode" in str(e.value)
+        assert not np.isnan(scene.render()).any()
     finally:
         scene.close()
-    ref = sf.to_oracle(world, cam).render()
-    rs, rf = sf.compare(strict, ref), sf.compare(fast, ref)
-    print(f"[parity] {name} {w}x{h}: strict {rs}")
-    print(f"[parity] {name} {w}x{h}: fast   {rf}")
-    assert rs["nan"] == 0 and rs["max_8bit"] <= 1 and rs["max_abs"] < F64_TOL, rs
-    assert rf["nan"] == 0 and rf["max_8bit"] <= 1 and rf["pixels_over_1"] == 0, rf
-    assert rf["max_abs"] < 1e-3, rf  # (thin-threshold flips aside, the flavours agree to ~1e-12)
