@@ -252,7 +252,8 @@ typedef struct rtc_scene_info {
     uint32_t committed, device;
     uint64_t device_bytes; /* all replicas */
     uint32_t n_devices;    /* replicas (rtc_scene_commit_devices) */
-    uint32_t pad;
+    uint32_t n_heavy_tiles; /* 8x8 tiles of the whole frame that show a transparent object (the static schedule may render
+                              them in parts) */
 } rtc_scene_info;
 int rtc_scene_get_info(rtc_scene *scene, rtc_scene_info *out);
 

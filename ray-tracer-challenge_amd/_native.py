@@ -94,7 +94,7 @@ class SceneInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "hsize", "vsize", "n_prims", "n_unbounded", "n_bvh_nodes", "n_xforms", "n_materials", "n_lights",
         "n_patterns", "n_triangles", "bvh_max_depth", "bvh_max_leaf", "committed", "device")] + [
-        ("device_bytes", C.c_uint64), ("n_devices", C.c_uint32), ("pad", C.c_uint32)]
+        ("device_bytes", C.c_uint64), ("n_devices", C.c_uint32), ("n_heavy_tiles", C.c_uint32)]
 
 
 class ItemInfo(C.Structure):

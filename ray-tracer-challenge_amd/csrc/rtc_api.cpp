@@ -460,17 +460,27 @@ static int launch_on(Scene &s, DeviceReplica &r, const DRenderParams &p, const r
     }
     r.last_work = work;
     DRenderParams pp = p;
-    // (the tile order was worked out for the whole frame: shares of a frame keep the raster order)
+    // Tile order, heaviest tiles first.  The static schedule may render the heavy ones in parts whose free lanes take over
+    // waiting rays (rtc_types.h): pixels then depend on which lane traced which part of a ray tree to ~1e-16, so
+    // exchange = 1 (the bit-reproducible frame) keeps whole tiles.  The persistent schedule always takes whole tiles.
+    pp.tile_perm = nullptr, pp.n_heavy = 0, pp.part_shift = 0;
+    uint32_t n_heavy = 0;
     const bool whole = p.tile_count <= 1 && (size_t)p.tiles_x * p.tiles_y == s.tile_perm.size();
-    pp.tile_perm = whole ? r.d_tile_perm : nullptr;
-    if (!whole && p.tile_count > 1 && !s.tile_score.empty()) {
+    if (whole) {
+        pp.tile_perm = r.d_tile_perm;
+        n_heavy = s.n_heavy_tiles;
+    } else if (p.tile_count > 1 && !s.tile_score.empty()) {
         // a share of the frame (one rank's or one replica's interleaved row tiles): its tiles in the order of the whole
         // frame's weights.  Built and uploaded at the first launch with this share -- the one allocation a render entry
         // point makes after commit, which is why the allocation-free entry point only uses an order that exists already.
-        const bool have = r.d_share_perm && r.share_key[0] == p.tile_rows && r.share_key[1] == p.tile_index &&
-                          r.share_key[2] == p.tile_count && r.n_share_perm == p.tiles_x * p.tiles_y;
+        // Every share keeps a buffer of its own (never rewritten): a launch of another share that is still in flight on
+        // another stream goes on reading its own order.
+        const uint32_t n = p.tiles_x * p.tiles_y;
+        DeviceReplica::SharePerm *have = nullptr;
+        for (DeviceReplica::SharePerm &sp : r.share_perms)
+            if (sp.key[0] == p.tile_rows && sp.key[1] == p.tile_index && sp.key[2] == p.tile_count && sp.n_tiles == n) have = &sp;
         if (!have && !refuse_oversize) {
-            const uint32_t n = p.tiles_x * p.tiles_y, gx = (s.hsize + 7u) / 8u, gy = (s.vsize + 7u) / 8u;
+            const uint32_t gx = (s.hsize + 7u) / 8u, gy = (s.vsize + 7u) / 8u;
             std::vector<int32_t> score(n);
             for (uint32_t ty = 0; ty < p.tiles_y; ty++) {
                 const uint32_t l = 8u * ty, k = l / p.tile_rows;
@@ -481,21 +491,34 @@ static int launch_on(Scene &s, DeviceReplica &r, const DRenderParams &p, const r
             std::vector<uint32_t> perm(n);
             for (uint32_t t = 0; t < n; t++) perm[t] = t;
             std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t c) { return score[a] > score[c]; });
-            if (r.n_share_perm < n) {
-                if (r.d_share_perm) (void)hipFree(r.d_share_perm);
-                r.d_share_perm = nullptr, r.n_share_perm = 0;
-                if (hipMalloc((void **)&r.d_share_perm, sizeof(uint32_t) * n) != hipSuccess) r.d_share_perm = nullptr;
+            DeviceReplica::SharePerm sp{{p.tile_rows, p.tile_index, p.tile_count}, n, nullptr, 0};
+            for (uint32_t t = 0; t < n; t++) sp.n_heavy += score[t] >= RTC_HEAVY_TILE_SCORE ? 1u : 0u;
+            if (hipMalloc((void **)&sp.d_perm, sizeof(uint32_t) * n) == hipSuccess &&
+                hipMemcpy(sp.d_perm, perm.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice) == hipSuccess) {
+                r.share_perms.push_back(sp);
+                have = &r.share_perms.back();
+            } else {  // (no order: the raster order is always correct)
+                if (sp.d_perm) (void)hipFree(sp.d_perm);
+                (void)hipGetLastError();
             }
-            if (r.d_share_perm && hipMemcpy(r.d_share_perm, perm.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice) == hipSuccess) {
-                r.n_share_perm = n;
-                r.share_key[0] = p.tile_rows, r.share_key[1] = p.tile_index, r.share_key[2] = p.tile_count;
-                pp.tile_perm = r.d_share_perm;
-            } else {
-                r.share_key[2] = 0;  // (no order: the raster order is always correct)
-            }
-        } else if (have) {
-            pp.tile_perm = r.d_share_perm;
         }
+        if (have) pp.tile_perm = have->d_perm, n_heavy = have->n_heavy;
+    }
+    if (!p.persistent && p.share != 0u && pp.tile_perm && n_heavy > 0) {
+        // Parts per heavy tile.  Splitting shortens a heavy tile's critical path (cover.yaml at 1080p, the band through
+        // the glass sphere alone: 1.6 ms whole, 0.5 ms in quarters) and costs instructions (the lanes of a part sit in
+        // different blocks of the state machine: about twice the wave-cycles in quarters), so it pays while the device
+        // has room.  Calibrated on cover.yaml and reflective_world.yaml from 320x180 to 3840x2160
+        // (profiles/r3_ab/r3_parts_ladder.txt; "heavy" is generous -- projected bounding boxes): quarters up to a third
+        // of the resident waves' worth of heavy tiles, halves up to twice the resident waves, whole tiles beyond.
+        // RTC_TILE_SPLIT = 1 / 2 / 4 forces the number of parts.
+        const int forced = getenv("RTC_TILE_SPLIT") ? atoi(getenv("RTC_TILE_SPLIT")) : 0;  // (read per launch: an A/B knob)
+        const uint64_t slots = (uint64_t)r.n_cu * 4u * RTC_MIN_WAVES;
+        uint32_t shift = (uint64_t)n_heavy * 3u <= slots ? 2u : ((uint64_t)n_heavy <= 2u * slots ? 1u : 0u);
+        if (forced == 1) shift = 0;
+        if (forced == 2) shift = 1;
+        if (forced == 4) shift = 2;
+        if (shift) pp.n_heavy = n_heavy, pp.part_shift = shift;
     }
     return launch_render(r.dscene, pp, d_rgb, r.d_stats, work, r.n_cu,
                                                             o.collect_stats != 0, st, &r.last_launch_id, refuse_oversize);
@@ -851,6 +874,7 @@ int rtc_scene_get_info(rtc_scene *scene, rtc_scene_info *out) {
     out->device = (uint32_t)s.device;
     out->device_bytes = s.device_bytes;
     out->n_devices = (uint32_t)s.reps.size();
+    out->n_heavy_tiles = s.n_heavy_tiles;
     return RTC_OK;
 }
 

@@ -65,9 +65,6 @@ namespace rtc {
 #ifndef RTC_KILL_DEAD
 #define RTC_KILL_DEAD 1  // end the live ranges of the traversal's per-pass state across the state machine (see there)
 #endif
-#ifndef RTC_MIN_WAVES
-#define RTC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for
-#endif
 
 struct V3 {
     double x, y, z;
@@ -869,6 +866,23 @@ DEV double lane_f64(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// index of the k-th (0-based) set bit of a wave-uniform mask, k per lane (k < popcount(m))
+DEV unsigned kth_set_bit(unsigned long long m, unsigned k) {
+    const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+    const unsigned c = (unsigned)__popc(lo);
+    unsigned w = k < c ? lo : hi, base = k < c ? 0u : 32u;
+    k = k < c ? k : k - c;
+#pragma unroll
+    for (unsigned sh = 16u; sh != 0u; sh >>= 1) {
+        const unsigned n = (unsigned)__popc(w & ((1u << sh) - 1u));
+        const bool up = k >= n;
+        w = up ? w >> sh : w;
+        base += up ? sh : 0u;
+        k -= up ? n : 0u;
+    }
+    return base;
+}
+
 // The megakernel.  Per lane it is a small state machine around ONE intersection pass:
 //   MODE_CLOSEST   World::color_at's closest hit for a primary / reflect / refract ray
 //   MODE_CONTAINER second pass over the same ray for n1/n2 (only for transparent hits)
@@ -928,6 +942,9 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
     // tree does not idle the other 63 (camera.rs:72-85 parallelises over rows with the same dynamic flavour).
     bool alive = false;
     unsigned pix = 0;               // tile * 64 + position in tile
+    // static schedule, wave-uniform: this workgroup renders a PART of a heavy tile (32 or 16 pixels); its other lanes take
+    // over waiting refracted rays from the first round on (rtc_types.h, RTC_HEAVY_TILE_SCORE)
+    bool in_parts = false;
     // wave-uniform: unassigned pixels of the tile in hand.  Wave b starts with tile b (no counter traffic while
     // the grid starts up); tiles from prm.dyn_base (= the grid size) on are drawn from the counters.
     unsigned r_next = (PERSISTENT && prm.tile_perm ? prm.tile_perm[blockIdx.x] : blockIdx.x) * 64u, r_end = r_next + 64u;
@@ -1060,7 +1077,14 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
         const V3 color = get_color();
         double *px = out + ((size_t)l * s.hsize + x) * 3u;
-        if (PERSISTENT && shared) {
+        if (!PERSISTENT && in_parts) {
+            // every part of this pixel's ray tree is traced by lanes of THIS wave (the pixel was zeroed when the wave
+            // started): the parts are added where the wave's stores went, in the L2 of its own XCD -- workgroup scope,
+            // no fence, no write-back
+            __hip_atomic_fetch_add(px + 0, color.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(px + 1, color.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(px + 2, color.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (shared) {
             // one of several lanes that traced parts of this pixel's ray tree (the pixel was zeroed when the first
             // part was handed over): the order of these few additions is the only run-to-run freedom of a frame
             atomicAdd(px + 0, color.x), atomicAdd(px + 1, color.y), atomicAdd(px + 2, color.z);
@@ -1095,6 +1119,13 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         px[0] = 0., px[1] = 0., px[2] = 0.;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the stores are in L2 before any lane adds to them)
     };
+    auto zero_pixel_local = [&]() {
+        const unsigned tile = prm.tile_order ? n_tiles - 1u - (pix >> 6) : (pix >> 6), q = pix & 63u;
+        const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
+        const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
+        double *px = out + ((size_t)l * s.hsize + x) * 3u;
+        px[0] = 0., px[1] = 0., px[2] = 0.;
+    };
     // a per-lane bound was exceeded: the host finds this launch's id in the flag word and reports RTC_ERR_OVERFLOW
     auto flag_overflow = [&]() { wb_store(work + RTC_WORK_FLAG, prm.launch_id); };
     if (PERSISTENT && prm.share && lane == 0) atomicAdd(work + RTC_WORK_BUSY, 1u);
@@ -1103,10 +1134,20 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
     unsigned share_round = 0;  // wave-uniform: varies the waves probed for hunger
     bool rendered = false;
     if (!PERSISTENT) {
-        // static schedule: workgroup b renders tile b and nothing else
-        pix = (prm.tile_perm ? prm.tile_perm[blockIdx.x] : blockIdx.x) * 64u + lane;
-        init_pixel();
+        // static schedule: workgroup b renders one tile of the list, or one part of one of its first n_heavy tiles
+        const unsigned parts = 1u << prm.part_shift, b = blockIdx.x, head = prm.n_heavy << prm.part_shift;
+        in_parts = b < head;
+        const unsigned entry = in_parts ? b >> prm.part_shift : b - head + prm.n_heavy;
+        const unsigned part_lanes = in_parts ? RTC_WAVE / parts : RTC_WAVE;
+        pix = (prm.tile_perm ? prm.tile_perm[entry] : entry) * 64u + (in_parts ? (b & (parts - 1u)) * part_lanes : 0u) + lane;
+        if (lane < part_lanes) {
+            init_pixel();
+            if (in_parts && alive) {
+                zero_pixel_local();  // (the parts of its ray tree are ADDED to it, see write_pixel)
+            }
+        }
         rendered = alive;
+        if (in_parts) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the zeros are in L2 before any addition)
     }
 
     // STATS only: stage timing.  WCNT adds a wave-level quantity once (lane 0 carries it).
@@ -1192,37 +1233,46 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
             // over the oldest waiting ray (the largest untraced subtree) of a busy lane of the same wave. ----
             // (prm.share == 0 turns BOTH hand-overs off: every pixel is then traced by one lane from start to end and the
             // frame is bit-reproducible, like the static schedule's)
-            if (PERSISTENT && prm.share && exhausted && r_next == r_end) {
-                unsigned long long recv = __ballot(!alive);
-                unsigned long long don = __ballot(alive && sp > 0);
-                while (recv != 0ull && don != 0ull) {
-                    const int dl = __ffsll((long long)don) - 1, rl = __ffsll((long long)recv) - 1;  // wave-uniform
-                    don &= don - 1ull, recv &= recv - 1ull;
+            if ((PERSISTENT && prm.share && exhausted && r_next == r_end) || (!PERSISTENT && in_parts)) {
+                // every free lane is matched with a lane that has a ray waiting -- the k-th free lane with the k-th such
+                // lane -- and ALL pairs move at once: the receiver pulls the donor's oldest waiting ray across the wave
+                // (ds_bpermute), the donor drops it from its ring
+                const unsigned long long recv = __ballot(!alive);
+                const bool may_give = alive && sp > 0;
+                const unsigned long long don = __ballot(may_give);
+                const unsigned n_recv = (unsigned)__popcll(recv), n_don = (unsigned)__popcll(don);
+                const unsigned n_pairs = n_recv < n_don ? n_recv : n_don;
+                if (n_pairs != 0u) {
+                    const unsigned rank_r = __builtin_amdgcn_mbcnt_hi((unsigned)(recv >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)recv, 0u));
+                    const unsigned rank_d = __builtin_amdgcn_mbcnt_hi((unsigned)(don >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)don, 0u));
+                    const bool is_don = may_give && rank_d < n_pairs;
+                    const bool is_recv = !alive && rank_r < n_pairs;
+                    const int src = is_recv ? (int)kth_set_bit(don, rank_r) : (int)lane;
                     Pending q;
                     q.o = q.d = mk(0., 0., 0.), q.w = 0., q.remaining = 0;
                     double qm = 0.;
-                    if ((int)lane == dl) {
+                    if (is_don) {
                         q = pend_at(pbase);
                         if (STATS) qm = pend_mult[pbase];
                         pbase = (pbase + 1) & (RTC_MAX_DEPTH_STACK - 1);
                         sp--;
-                        if (!shared) {
-                            zero_pixel();
-                            shared = true;
-                        }
+                        if (PERSISTENT && !shared) zero_pixel();
+                        shared = true;
                     }
-                    const unsigned qpix = lane_u32(pix, dl);
-                    const int qrem = (int)lane_u32((unsigned)q.remaining, dl);
-                    const V3 qo = mk(lane_f64(q.o.x, dl), lane_f64(q.o.y, dl), lane_f64(q.o.z, dl));
-                    const V3 qd = mk(lane_f64(q.d.x, dl), lane_f64(q.d.y, dl), lane_f64(q.d.z, dl));
-                    const double qw = lane_f64(q.w, dl);
-                    const double qmult = STATS ? lane_f64(qm, dl) : 0.;
-                    if ((int)lane == rl) adopt(qpix, qo, qd, qw, qmult, qrem);
+                    const unsigned qpix = (unsigned)__shfl((int)pix, src, RTC_WAVE);
+                    const int qrem = __shfl(q.remaining, src, RTC_WAVE);
+                    const V3 qo = mk(__shfl(q.o.x, src, RTC_WAVE), __shfl(q.o.y, src, RTC_WAVE), __shfl(q.o.z, src, RTC_WAVE));
+                    const V3 qd = mk(__shfl(q.d.x, src, RTC_WAVE), __shfl(q.d.y, src, RTC_WAVE), __shfl(q.d.z, src, RTC_WAVE));
+                    const double qw = __shfl(q.w, src, RTC_WAVE);
+                    const double qmult = STATS ? __shfl(qm, src, RTC_WAVE) : 0.;
+                    if (is_recv) adopt(qpix, qo, qd, qw, qmult, qrem);
                 }
                 // ---- and the waves that ran out of rays altogether take over waiting rays of other WAVES: a wave
                 // without work publishes its hunger, a wave with waiting rays claims one hungry wave per round
                 // (compare-and-swap on that wave's mailbox state) and moves its lanes' oldest waiting rays there. ----
-                const unsigned long long don2 = __ballot(alive && sp > 0);
+                const unsigned long long don2 = PERSISTENT ? __ballot(alive && sp > 0) : 0ull;
                 if (don2 != 0ull) {
                     int target = -1;
                     if (lane == 0 && wb_load(work + RTC_WORK_HUNGRY) != 0u) {
@@ -1588,7 +1638,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
             alive = false;
         }
         SUB_END(ST_BOX);
-        if (PERSISTENT && !alive) write_pixel();  // the lane is free for the next pixel
+        if ((PERSISTENT || in_parts) && !alive) write_pixel();  // the lane is free for the next pixel / waiting ray
 #if RTC_KILL_DEAD
         // A lane that went through the state machine is BETWEEN passes: the traversal's own state (cursor, stack pointer,
         // node in hand, the f32 form of the ray) and the fold's scratch values are dead for it -- the next pass sets them
@@ -1604,7 +1654,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         }  // if (alive)
         STAGE_END(ST_CYC_SHADE);
     }
-    if (!PERSISTENT && rendered) write_pixel();  // the whole tile at once
+    if (!PERSISTENT && !in_parts && rendered) write_pixel();  // the whole tile at once
 
 #ifdef RTC_TIMING_ONLY
     if (STATS && lane == 0) {
@@ -1702,8 +1752,10 @@ static void launch_variant(const DScene &scene, DRenderParams &params, double *d
         params.refill_min = RTC_WAVE;
         params.dyn_base = tiles;
         params.share = 0u, params.n_waves = tiles;
-        hipLaunchKernelGGL((k_render<STATS, GROUPS, PATTERNS, false, QNODES>), dim3(tiles), dim3(RTC_WAVE), 0, st, scene,
-                           params, d_rgb, ds, d_work);
+        // (one workgroup per tile; the first n_heavy tiles of the list take one per part)
+        hipLaunchKernelGGL((k_render<STATS, GROUPS, PATTERNS, false, QNODES>),
+                           dim3(tiles + params.n_heavy * ((1u << params.part_shift) - 1u)),
+                           dim3(RTC_WAVE), 0, st, scene, params, d_rgb, ds, d_work);
     }
 }
 

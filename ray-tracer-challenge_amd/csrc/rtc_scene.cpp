@@ -52,7 +52,10 @@ void Scene::release_device() {
         DeviceGuard g(r.device);
         for (void *p : r.allocs) (void)hipFree(p);
         if (r.d_canvas) (void)hipFree(r.d_canvas);
-        if (r.d_share_perm) (void)hipFree(r.d_share_perm);
+        for (DeviceReplica::SharePerm &sp : r.share_perms) {
+            if (sp.d_perm) (void)hipFree(sp.d_perm);
+        }
+        r.share_perms.clear();
         for (int k = 0; k < 2; k++) {
             if (r.wf.rays[k]) (void)hipFree(r.wf.rays[k]);
             if (r.wf.ctx[k]) (void)hipFree(r.wf.ctx[k]);
@@ -800,7 +803,7 @@ void Scene::build_bvh() {
 // onto the canvas (camera.rs:41-59 read backwards) -- and rendered in that order.  A heuristic: it changes when a tile
 // starts, never what it computes.
 void Scene::build_tile_order() {
-    tile_perm.clear(), tile_score.clear();
+    tile_perm.clear(), tile_score.clear(), n_heavy_tiles = 0;
     static const int enabled = getenv("RTC_TILE_SORT") ? atoi(getenv("RTC_TILE_SORT")) : 1;
     const uint32_t tx = (hsize + 7u) / 8u, ty = (vsize + 7u) / 8u;
     if (!enabled || (uint64_t)tx * ty < 2 || (uint64_t)tx * ty > (1u << 24)) return;
@@ -854,6 +857,7 @@ void Scene::build_tile_order() {
     for (uint32_t t = 0; t < tx * ty; t++) tile_perm[t] = t;
     std::stable_sort(tile_perm.begin(), tile_perm.end(), [&](uint32_t a, uint32_t c) { return score[a] > score[c]; });
     tile_score.swap(score);
+    for (uint32_t t : tile_perm) n_heavy_tiles += tile_score[t] >= RTC_HEAVY_TILE_SCORE ? 1u : 0u;  // (they come first)
 }
 
 // ---------------------------------------------------------------------------------------------

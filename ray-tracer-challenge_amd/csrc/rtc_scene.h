@@ -67,11 +67,16 @@ struct DeviceReplica {
     const uint32_t *d_tile_perm = nullptr;  // Scene::tile_perm on this device (or null)
     WfBuffers wf;
     uint32_t wf_generations = 0;  // generations of the most recent wavefront frame
-    // the same order for the most recent SHARE of the frame rendered here (rtc_render_opts.tile_*): built at the first
-    // launch with that share, kept until another share is asked for
-    uint32_t share_key[3] = {0, 0, 0};  // tile_rows, tile_index, tile_count
-    uint32_t *d_share_perm = nullptr;
-    uint32_t n_share_perm = 0;
+    // the same orders for the SHARES of the frame rendered here (rtc_render_opts.tile_*): each built and uploaded at the
+    // first launch with that share into a buffer of its own and kept until the scene is released -- a buffer is never
+    // rewritten, so launches of different shares that are still in flight on other streams keep reading their own
+    struct SharePerm {
+        uint32_t key[3];          // tile_rows, tile_index, tile_count
+        uint32_t n_tiles;         // tiles of the share
+        uint32_t *d_perm;         // the share's tiles in the order of their weights
+        uint32_t n_heavy;         // how many of them (the first ones) show a transparent object
+    };
+    std::vector<SharePerm> share_perms;
     uint32_t last_launch_id = 0;  // id of the most recent launch and the work buffer it used (overflow flag)
     unsigned *last_work = nullptr;
 };
@@ -127,6 +132,7 @@ struct Scene {
     // whole-frame tile order of the static schedule: tiles that show transparent / reflective objects first (empty: raster)
     std::vector<uint32_t> tile_perm;
     std::vector<int32_t> tile_score;  // the weights the order was sorted by, per whole-frame tile (empty: all alike)
+    uint32_t n_heavy_tiles = 0;  // tiles at the head of tile_perm that show a transparent object (RTC_HEAVY_TILE_SCORE)
     void build_tile_order();
     void *h_stage[3] = {nullptr, nullptr, nullptr};  // pinned staging buffers of rtc_render's device-to-host copy
     size_t stage_bytes = 0;

@@ -253,6 +253,15 @@ struct DScene {
 #endif
 #define RTC_LANE_LINES (RTC_RING_SLOTS + 1u)
 #define RTC_WORK_TOTAL_BYTES (RTC_WORK_RING_OFFSET + (RTC_RING_GLOBAL ? (size_t)RTC_MAX_WAVES * 64u * RTC_LANE_LINES * 64u : 0u))
+// Heavy tiles of the static schedule (they show a transparent object: a ray TREE per pixel, and refraction keeps the bounce
+// budget) may be rendered in 2 or 4 PARTS of 32 / 16 pixels, one wave each; the wave's other lanes take over waiting
+// refracted rays from the first round on, so the tile's critical path is nearer the depth of its ray trees than their
+// size.  The heavy tiles are the first DRenderParams::n_heavy entries of the (sorted) tile list; the launcher picks the
+// number of parts by how many such tiles there are for the device's resident waves (rtc_api.cpp, launch_on).
+#define RTC_HEAVY_TILE_SCORE 4  // Scene::build_tile_order: weight of one transparent primitive
+#ifndef RTC_MIN_WAVES
+#define RTC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (static schedule)
+#endif
 enum { RTC_MB_IDLE = 0, RTC_MB_HUNGRY = 1, RTC_MB_FILLING = 2, RTC_MB_FULL = 3, RTC_MB_CLOSED = 4 };
 
 struct DRenderParams {
@@ -271,9 +280,9 @@ struct DRenderParams {
     uint32_t leaf_den;          // primitive tests run when at least 1/leaf_den of the traversing lanes wait at a leaf
     uint32_t launch_id;         // process-wide unique, never 0: what an overflowing lane stores into work[RTC_WORK_FLAG]
     uint32_t max_rays;          // rays one lane may trace for one pixel (or adopted subtree) before it gives up
-    uint32_t pad1;
+    uint32_t part_shift;        // 0, 1 or 2
     uint32_t refuse_oversize;   // host only: 1 = a grid beyond RTC_MAX_WAVES with the exchange on is an error (2 = it was)
-    uint32_t pad0;
+    uint32_t n_heavy;           // static schedule: the first n_heavy tiles of the list are rendered in 1 << part_shift parts
     // static schedule, whole frame: workgroup b renders tile tile_perm[b] -- the tiles that show transparent or reflective
     // objects first, because a frame of few such objects lasts as long as its slowest tile and that tile should not
     // start last (null: workgroup b renders tile b)

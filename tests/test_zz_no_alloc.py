@@ -50,8 +50,11 @@ def test_static_scratch_entry_point_equals_render_device_twice_in_a_row():
             a2, b2 = _both(scene, cam, schedule=2)
             assert float(np.max(np.abs(a2 - b2))) < 1e-12 and float(np.max(np.abs(a - b2))) < 1e-12
             # static schedule: only the overflow flag of the scratch is used
-            a3, b3 = _both(scene, cam, schedule=1)
+            a3, b3 = _both(scene, cam, schedule=1, exchange=1)
             assert np.array_equal(a3, b3) and np.array_equal(a3, a)
+            # (default: quarter tiles with in-wave hand-over -- deterministic, and within rounding of the above)
+            a4, b4 = _both(scene, cam, schedule=1)
+            assert np.array_equal(a4, b4) and float(np.max(np.abs(a4 - a))) < 1e-12
         # the overflow flag lives in the shared array too: a capped launch reports, the next clean one does not
         scene, cam = scenes[1]
         buf = torch.zeros((cam.vsize, cam.hsize, 3), dtype=torch.float64, device="cuda:0")
