@@ -43,6 +43,10 @@ namespace rtc {
 #define RTC_MAX_RAYS_PER_PIXEL 65536
 #endif
 #define RTC_NO_NODE ((int)0x80000000)  // "no node in hand": the next step pops the stack
+#define RTC_DONE ((int)0x80000001)     // deferred leaves: the stack is empty, the run in hand is all that is left of the pass
+#ifndef RTC_DEFER_LEAVES
+#define RTC_DEFER_LEAVES 1
+#endif
 #ifndef RTC_STEPS_PER_CHECK
 #define RTC_STEPS_PER_CHECK 8         // traversal steps between two looks at the wave's occupancy
 #endif
@@ -1242,7 +1246,35 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                 const unsigned long long don = __ballot(may_give);
                 const unsigned n_recv = (unsigned)__popcll(recv), n_don = (unsigned)__popcll(don);
                 const unsigned n_pairs = n_recv < n_don ? n_recv : n_don;
-                if (n_pairs != 0u) {
+                if (PERSISTENT) {
+                    // (persistent grid, end of frame: pairs are few and the kernel is held to 128 registers -- one pair
+                    // at a time through v_readlane, which keeps the ray in scalar registers on its way)
+                    unsigned long long rm = recv, dm = don;
+                    while (rm != 0ull && dm != 0ull) {
+                        const int dl = __ffsll((long long)dm) - 1, rl = __ffsll((long long)rm) - 1;  // wave-uniform
+                        dm &= dm - 1ull, rm &= rm - 1ull;
+                        Pending q;
+                        q.o = q.d = mk(0., 0., 0.), q.w = 0., q.remaining = 0;
+                        double qm = 0.;
+                        if ((int)lane == dl) {
+                            q = pend_at(pbase);
+                            if (STATS) qm = pend_mult[pbase];
+                            pbase = (pbase + 1) & (RTC_MAX_DEPTH_STACK - 1);
+                            sp--;
+                            if (!shared) {
+                                zero_pixel();
+                                shared = true;
+                            }
+                        }
+                        const unsigned qpix = lane_u32(pix, dl);
+                        const int qrem = (int)lane_u32((unsigned)q.remaining, dl);
+                        const V3 qo = mk(lane_f64(q.o.x, dl), lane_f64(q.o.y, dl), lane_f64(q.o.z, dl));
+                        const V3 qd = mk(lane_f64(q.d.x, dl), lane_f64(q.d.y, dl), lane_f64(q.d.z, dl));
+                        const double qw = lane_f64(q.w, dl);
+                        const double qmult = STATS ? lane_f64(qm, dl) : 0.;
+                        if ((int)lane == rl) adopt(qpix, qo, qd, qw, qmult, qrem);
+                    }
+                } else if (n_pairs != 0u) {
                     const unsigned rank_r = __builtin_amdgcn_mbcnt_hi((unsigned)(recv >> 32),
                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)recv, 0u));
                     const unsigned rank_d = __builtin_amdgcn_mbcnt_hi((unsigned)(don >> 32),
@@ -1258,8 +1290,6 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                         if (STATS) qm = pend_mult[pbase];
                         pbase = (pbase + 1) & (RTC_MAX_DEPTH_STACK - 1);
                         sp--;
-                        if (PERSISTENT && !shared) zero_pixel();
-                        shared = true;
                     }
                     const unsigned qpix = (unsigned)__shfl((int)pix, src, RTC_WAVE);
                     const int qrem = __shfl(q.remaining, src, RTC_WAVE);
