@@ -39,7 +39,7 @@ enum rtc_status {
     RTC_ERR_STATE = 5,          /* scene not committed / already committed */
     RTC_ERR_IO = 6,             /* file could not be read / written */
     RTC_ERR_PARSE = 7,          /* YAML / OBJ syntax or semantic error (parse_scene ParseError) */
-    RTC_ERR_OVERFLOW = 8        /* a per-lane bound of the kernel was exceeded (see rtc_stats.overflow) */
+    RTC_ERR_OVERFLOW = 8        /* a per-lane bound of the kernel was exceeded: the frame is not valid (see rtc_render) */
 };
 
 /* ShapeType, shape.rs:27-38.  Triangles are added with rtc_scene_add_triangles, groups with
@@ -175,7 +175,11 @@ int rtc_scene_end_group(rtc_scene *scene);
  * RTC_ERR_STATE unless exactly two were added.  Like the reference's Csg the node has no transformation and no
  * material of its own.  Triangles cannot be direct children (Triangle::material() panics under a Csg parent,
  * shape.rs:1521-1523); put them in a group.  Equal-t records of the two operands are ordered by depth-first shape
- * index (the reference sorts them with sort_unstable_by, shape.rs:2232: unspecified). */
+ * index (the reference sorts them with sort_unstable_by, shape.rs:2232: unspecified).
+ * Limits the reference does not have: a tree is ONE entry of the intersection structures, so a ray that reaches the
+ * tree's bounding box tests every leaf shape of the tree (no hierarchy inside a tree: cost linear in its leaves), and one
+ * ray may collect at most 32 intersection records from one tree (a Csg of more than ~16 convex shapes along one ray):
+ * beyond that the launch reports RTC_ERR_OVERFLOW. */
 int rtc_scene_begin_csg(rtc_scene *scene, int operation);
 int rtc_scene_end_csg(rtc_scene *scene);
 /* Sphere/Plane/Cube/Cylinder/Cone::new, shape.rs:179, 498, 653, 873, 1190.  minimum/maximum/closed are used
@@ -208,9 +212,12 @@ int rtc_scene_commit_devices(rtc_scene *scene, const int *devices, uint32_t n_de
  * rows are written (the rest of rgb_out is zeroed). */
 int rtc_render(rtc_scene *scene, const rtc_render_opts *opts, double *rgb_out, rtc_stats *stats);
 /* Errors of the render entry points beyond argument checks: RTC_ERR_OVERFLOW when a lane exceeded one of the
- * kernel's per-lane bounds (max_rays_per_pixel, pending refractions, traversal stack): rtc_render reports it itself
- * (the canvas is still written; the pixels concerned are NaN); after the asynchronous rtc_render_device ask
- * rtc_scene_check().  The calls leave the caller's current HIP device as they found it. */
+ * kernel's per-lane bounds (max_rays_per_pixel; more than 8 waiting refracted rays; a traversal stack deeper than 96
+ * entries; more than 32 records of one ray in one Csg tree; a full queue of the wavefront schedule): rtc_render
+ * reports it itself; after the asynchronous rtc_render_device ask rtc_scene_check().  The canvas is still written,
+ * but the pixels concerned are UNDEFINED: NaN where max_rays_per_pixel was exceeded, otherwise a finite colour that
+ * lacks the contributions that were dropped -- discard the frame.  The calls leave the caller's current HIP device as
+ * they found it. */
 
 /* Synchronises the scene's device and reports the state of the most recent launch on this scene: RTC_OK,
  * RTC_ERR_OVERFLOW (see above) or RTC_ERR_HIP (the kernel faulted). */
@@ -221,7 +228,8 @@ int rtc_scene_check(rtc_scene *scene);
  * ascending canvas-row order (every row, including an all-black last canvas row if it is owned).
  * Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).  Whole-frame calls allocate nothing; the FIRST
  * call with a given share of the frame (tile_rows / tile_index / tile_count) uploads that share's tile order (one small
- * hipMalloc + synchronous copy), later calls with the same share allocate nothing. */
+ * hipMalloc + synchronous copy into a buffer of its own, kept until the scene is destroyed: launches of other shares
+ * that are still in flight are not disturbed), later calls with the same share allocate nothing. */
 int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream);
 /* rtc_render_device for callers that cannot allocate and cannot rely on memory the library allocated for this
  * scene's launches: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO
@@ -232,8 +240,11 @@ int rtc_render_device(rtc_scene *scene, const rtc_render_opts *opts, double *d_r
  * GPU, held until the process ends.  Limits: collect_stats is refused; frames beyond 2^26 8x8 tiles are refused (as by
  * every entry point); the persistent grid is capped at RTC_STATIC_SCRATCH_WAVES resident waves (MI355X: 3072).  Every
  * scene on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race -- serialise
- * them.  The call itself makes no hipMalloc / hipFree / allocating runtime call (a share of the frame whose tile order
- * has not been uploaded by an earlier rtc_render / rtc_render_device call is rendered in raster order). */
+ * them.  The overflow flag lives in that array too and names the launch that raised it: ask rtc_scene_check(scene) BEFORE
+ * the next static launch of ANY scene on the same GPU, or a later launch's overflow replaces the word and this one's
+ * goes unreported.  The call itself makes no hipMalloc / hipFree / allocating runtime call (a share of the frame whose
+ * tile order has not been uploaded by an earlier rtc_render / rtc_render_device call is rendered in raster order; the
+ * first launch of a kernel variant in a process still loads its code object, as any first launch does). */
 #define RTC_STATIC_SCRATCH_WAVES 4096u
 #define RTC_STATIC_SCRATCH_BYTES (36864u + RTC_STATIC_SCRATCH_WAVES * 64u * (80u + 576u))
 int rtc_render_device_static(rtc_scene *scene, const rtc_render_opts *opts, double *d_rgb, void *hip_stream);

@@ -538,8 +538,8 @@ static int read_overflow(DeviceReplica &r, bool &overflow) {
 }
 
 static int overflow_error() {
-    set_error("a lane exceeded a per-lane bound of the kernel (rays per pixel, waiting refracted rays or traversal "
-              "stack): the pixels concerned are NaN");
+    set_error("a lane exceeded a per-lane bound of the kernel (rays per pixel, waiting refracted rays, traversal stack, "
+              "records per Csg tree): the pixels concerned are undefined (NaN for the ray cap), discard the frame");
     return RTC_ERR_OVERFLOW;
 }
 
@@ -788,9 +788,11 @@ int rtc_render(rtc_scene *scene, const rtc_render_opts *opts, double *rgb_out, r
         // ---- one process, several GPUs (camera.rs:72-91): replica k renders the interleaved 8-row
         // tiles t % N == k into a compact buffer on its own device and stream; each buffer then moves into the
         // canvas on the primary device with ONE strided device-to-device copy over its xGMI link (7 peers = 7
-        // distinct links into device 0; no ring, no reduction), and the canvas goes to the host once. ----
+        // distinct links into device 0; no ring, no reduction), and the canvas goes to the host once.  The copy of a
+        // replica starts when ITS kernel ends, so copies overlap the renders of slower replicas; a replica's own render
+        // and copy do not overlap -- a launch is monolithic, and cutting it into bands would cost the heaviest-first tile
+        // order, which is worth more wherever the render is not dwarfed by a 25 MB copy. ----
         const uint32_t TILE = 8;
-        const auto t0 = std::chrono::steady_clock::now();
         std::vector<DRenderParams> ps(n_rep);
         std::vector<rtc_render_opts> os(n_rep);
         for (uint32_t k = 0; k < n_rep; k++) {
@@ -806,22 +808,42 @@ int rtc_render(rtc_scene *scene, const rtc_render_opts *opts, double *rgb_out, r
             if (ps[k].local_rows == 0) continue;
             DeviceGuard g(r.device);
             if (k > 0 && (rc = ensure_canvas(r, row_bytes * ps[k].local_rows))) break;
+            (void)hipEventRecord((hipEvent_t)r.ev_start, (hipStream_t)r.stream);
             rc = launch_on(s, r, ps[k], os[k], compact(k), r.d_work, (hipStream_t)r.stream);
+            (void)hipEventRecord((hipEvent_t)r.ev_stop, (hipStream_t)r.stream);
         }
         for (uint32_t k = 0; k < n_rep && rc == RTC_OK; k++) {
             DeviceReplica &r = s.reps[k];
+            if (ps[k].local_rows == 0) continue;
             DeviceGuard g(r.device);
-            // compact tile j of replica k is canvas tile j * N + k; one peer copy per tile, on the replica's stream
+            // compact tile j of replica k is canvas tile j * N + k: a 2-d copy whose "rows" are whole tiles (TILE canvas
+            // rows = tile_bytes, contiguous on both sides), source pitch one tile, destination pitch N tiles; the last
+            // tile of the frame may be shorter than TILE rows and goes separately
             const size_t tile_bytes = row_bytes * TILE;
-            for (uint32_t done = 0, j = 0; done < ps[k].local_rows && rc == RTC_OK; done += TILE, j++) {
-                const uint32_t rows = std::min(TILE, ps[k].local_rows - done);
-                char *dst = (char *)r0.d_canvas + ((size_t)j * n_rep + k) * tile_bytes;
-                const char *src = (const char *)compact(k) + (size_t)j * tile_bytes;
-                const hipError_t e = hipMemcpyPeerAsync(dst, r0.device, src, r.device, row_bytes * rows, (hipStream_t)r.stream);
+            const uint32_t full_tiles = ps[k].local_rows / TILE, rest_rows = ps[k].local_rows % TILE;
+            char *dst = (char *)r0.d_canvas + (size_t)k * tile_bytes;
+            const char *src = (const char *)compact(k);
+            hipError_t e = hipSuccess;
+            if (full_tiles > 0) {
+                e = hipMemcpy2DAsync(dst, (size_t)n_rep * tile_bytes, src, tile_bytes, tile_bytes, full_tiles,
+                                     hipMemcpyDeviceToDevice, (hipStream_t)r.stream);
                 if (e != hipSuccess) {
-                    set_error("device-to-device copy of replica %u's tiles failed: %s", k, hipGetErrorString(e));
-                    rc = RTC_ERR_HIP;
+                    // (a runtime that refuses the strided form between these two devices -- no peer mapping: one peer
+                    // copy per tile, which every pair of devices supports)
+                    (void)hipGetLastError();
+                    e = hipSuccess;
+                    for (uint32_t j = 0; j < full_tiles && e == hipSuccess; j++)
+                        e = hipMemcpyPeerAsync(dst + (size_t)j * n_rep * tile_bytes, r0.device, src + (size_t)j * tile_bytes,
+                                               r.device, tile_bytes, (hipStream_t)r.stream);
                 }
+            }
+            if (e == hipSuccess && rest_rows > 0)
+                e = hipMemcpyPeerAsync(dst + (size_t)full_tiles * n_rep * tile_bytes, r0.device,
+                                       src + (size_t)full_tiles * tile_bytes, r.device, row_bytes * rest_rows,
+                                       (hipStream_t)r.stream);
+            if (e != hipSuccess) {
+                set_error("device-to-device copy of replica %u's tiles failed: %s", k, hipGetErrorString(e));
+                rc = RTC_ERR_HIP;
             }
         }
         for (uint32_t k = 0; k < n_rep; k++) {
@@ -832,7 +854,13 @@ int rtc_render(rtc_scene *scene, const rtc_render_opts *opts, double *rgb_out, r
             }
         }
         if (rc) return rc;
-        ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        // kernel time of the frame: the slowest replica's, from the events around its launch on its own stream
+        for (uint32_t k = 0; k < n_rep; k++) {
+            if (ps[k].local_rows == 0) continue;
+            DeviceGuard g(s.reps[k].device);
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, (hipEvent_t)s.reps[k].ev_start, (hipEvent_t)s.reps[k].ev_stop) == hipSuccess) ms = std::max(ms, t);
+        }
         rc = staged_download(s, (const char *)r0.d_canvas, row_bytes * s.vsize, nullptr,
                              [&](size_t off, const char *src, size_t n) { std::memcpy((char *)rgb_out + off, src, n); });
         if (rc) return rc;

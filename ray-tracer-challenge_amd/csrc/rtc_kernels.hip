@@ -751,9 +751,19 @@ DEV bool isect_csg(const DScene &s, int tree, const Ray &ray, Trace &T) {
 #ifndef RTC_LDS_STACK
 #define RTC_LDS_STACK 16
 #endif
+#ifndef RTC_STATIC_REGS
+#define RTC_STATIC_REGS 0  // A/B only (rejected): static schedule keeps colour / weight / Schlick factor in registers
+#endif
+#ifndef RTC_LDS_STACK_STATIC
+#define RTC_LDS_STACK_STATIC 6  // static schedule: see k_render
+#endif
 #ifndef RTC_LDS_TOP
 #define RTC_LDS_TOP 0
 #endif
+#ifndef RTC_LDS_TABLES
+#define RTC_LDS_TABLES 0
+#endif
+#define RTC_LDS_TAB_DOUBLES 288  // 2304 bytes: cover.yaml's 19 materials and 2 lights fit
 //  // BVH stack entries kept in LDS; deeper entries spill to a per-lane scratch array
 enum ParkSlot {
     PK_POINT = 0,   // h_point  (3)
@@ -907,9 +917,25 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                                                                      double *__restrict__ out,
                                                                      unsigned long long *__restrict__ stats,
                                                                      unsigned *__restrict__ work) {
-    __shared__ int bvh_stack[RTC_LDS_STACK * RTC_WAVE];
+    // BVH stack entries kept in LDS; deeper entries go to a per-lane scratch array.  The static schedule keeps 6: with
+    // near-child-first traversal few far children wait at a time even in hierarchies 18 levels deep, and the SIZE of a
+    // workgroup's LDS is what counts -- at 12 x 12.8 KB the CU's 160 KB are full to the last 6 KB, waves wait for a hole
+    // that fits and the device averages 10.3 instead of 12 resident waves per CU (SQ_WAVE_CYCLES; the same kernel with 4
+    // entries and 12 unused ones is as slow as with 16).  10.2 KB: cover 4K 3.68 -> 3.26 ms, cover 1080p 1.58 -> 1.41 ms,
+    // 30 000 spheres unchanged (profiles/r3_ab/r3_ab_sstack*.txt, r3_mid_probe.txt).
+    constexpr int LDS_STACK = PERSISTENT ? RTC_LDS_STACK : RTC_LDS_STACK_STATIC;
+    __shared__ int bvh_stack[LDS_STACK * RTC_WAVE];
+#ifdef RTC_LDS_PAD  // A/B only: unused LDS, to tell the effect of a workgroup's LDS SIZE from that of its stack's length
+    __shared__ int lds_pad[RTC_LDS_PAD * RTC_WAVE];
+    if (threadIdx.x == 0 && prm.depth == 0xffffffffu) lds_pad[0] = 1;
+    asm volatile("" ::"v"(&lds_pad[threadIdx.x]) : "memory");
+#endif
     constexpr bool SIDE = PERSISTENT && RTC_RING_GLOBAL && RTC_SIDE_SLOT;
-    __shared__ double parked[(SIDE ? PK_COUNT_SIDE : PK_COUNT) * RTC_WAVE];
+    // A/B only (rejected): the static schedule with colour, weight and Schlick factor in registers -- LDS 10.2 -> 7.7 KB, but
+    // the ten registers live across the traversal loop cost more than the LDS was worth (cover 4K 3.26 -> 3.67 ms,
+    // profiles/r3_ab/r3_ab_regs.txt)
+    constexpr bool REGS = !PERSISTENT && RTC_STATIC_REGS;
+    __shared__ double parked[((SIDE || REGS) ? PK_COUNT_SIDE : PK_COUNT) * RTC_WAVE];
 #if RTC_LDS_TOP
     // A/B only ("LDS staging"): the first RTC_LDS_TOP nodes of the breadth-first hierarchy -- its
     // top levels -- copied into LDS by every wave.  LDS is what bounds the occupancy (12.8 KB per wave x 12 waves of the
@@ -920,9 +946,53 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         for (int i = (int)threadIdx.x; i < n_top * 2; i += RTC_WAVE) top_nodes[i] = ((const uint4 *)s.bvh_q)[i];
 #endif
     const unsigned lane = threadIdx.x;
+#if RTC_LDS_TABLES
+    // A/B only ("light / material tables in LDS"; north_star's staging clause): the material and light
+    // tables of a SMALL scene copied into LDS by every wave of the static schedule and read from there by the state
+    // machine.  The default reads them through the vector L1 (per-lane indices) -- see the record for why that stays.
+    __shared__ double lds_tab[RTC_LDS_TAB_DOUBLES];
+    static_assert(sizeof(DMaterial) == 96 && sizeof(DLight) == 136, "table strides of the LDS copy");
+    const bool tab_ok = !PERSISTENT && s.n_materials * 12 + s.n_lights * 17 <= RTC_LDS_TAB_DOUBLES;
+    const int tab_lights = s.n_materials * 12;
+    if (tab_ok) {
+        for (int i = (int)lane; i < s.n_materials * 12; i += RTC_WAVE) lds_tab[i] = ((const double *)s.materials)[i];
+        for (int i = (int)lane; i < s.n_lights * 17; i += RTC_WAVE) lds_tab[tab_lights + i] = ((const double *)s.lights)[i];
+        __syncthreads();
+    }
+    auto mat_f64 = [&](int i, int k) { return tab_ok ? lds_tab[i * 12 + k] : ((const double *)(s.materials + i))[k]; };
+    auto load_material = [&](int i) {
+        DMaterial m = DMaterial();
+        if (tab_ok) {
+            double *md = (double *)&m;
+            for (int k = 0; k < 12; k++) md[k] = lds_tab[i * 12 + k];
+        } else {
+            m = s.materials[i];
+        }
+        return m;
+    };
+    auto load_light = [&](int i) {
+        DLight l = DLight();
+        if (tab_ok) {
+            double *ld = (double *)&l;
+            for (int k = 0; k < 17; k++) ld[k] = lds_tab[tab_lights + i * 17 + k];
+        } else {
+            l = s.lights[i];
+        }
+        return l;
+    };
+#define RTC_MAT_F64(i, k, field) mat_f64((i), (k))
+#define RTC_MAT_CASTS(i) (__double2loint(mat_f64((i), 10)) != 0)
+#define RTC_LOAD_MATERIAL(i) load_material(i)
+#define RTC_LOAD_LIGHT(i) load_light(i)
+#else
+#define RTC_MAT_F64(i, k, field) (s.materials[(i)].field)
+#define RTC_MAT_CASTS(i) (s.materials[(i)].casts_shadow != 0)
+#define RTC_LOAD_MATERIAL(i) (s.materials[(i)])
+#define RTC_LOAD_LIGHT(i) (s.lights[(i)])
+#endif
     int *const stack = &bvh_stack[lane];  // [entry][lane]: conflict free
     lds_f64 *const pk = (lds_f64 *)parked + lane;
-    int deep_stack[RTC_BVH_STACK - RTC_LDS_STACK];  // scratch memory: entries beyond the LDS part (rare)
+    int deep_stack[RTC_BVH_STACK - LDS_STACK];  // scratch memory: entries beyond the LDS part (rare)
 #ifdef RTC_POP_PROBE
     // measurement only (build with -DRTC_BRANCHFREE=0, read with collect_stats): entry distance of every waiting subtree,
     // to count the stack entries that are popped after the ray's limit has moved in front of them.  The counters of the
@@ -967,23 +1037,31 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         (Pending *)((char *)work + RTC_WORK_RING_OFFSET) + ((size_t)blockIdx.x * RTC_WAVE + threadIdx.x) * RTC_LANE_LINES;
     // the lane's side line behind its ring: colour[3], weight, Schlick factor (SIDE), else their LDS slots
     double *const side = (double *)(pend_global + RTC_RING_SLOTS);
-    auto get_color = [&]() { return SIDE ? mk(side[0], side[1], side[2]) : unpark3(pk, PK_COLOR); };
+    V3 reg_color = mk(0., 0., 0.);
+    double reg_w = 0., reg_kr = 0.;
+    auto get_color = [&]() { return REGS ? reg_color : SIDE ? mk(side[0], side[1], side[2]) : unpark3(pk, PK_COLOR); };
     auto set_color = [&](V3 v) {
-        if (SIDE)
+        if (REGS)
+            reg_color = v;
+        else if (SIDE)
             side[0] = v.x, side[1] = v.y, side[2] = v.z;
         else
             park3(pk, PK_COLOR, v);
     };
-    auto get_w = [&]() { return SIDE ? side[3] : (double)pk[PK_W * RTC_WAVE]; };
+    auto get_w = [&]() { return REGS ? reg_w : SIDE ? side[3] : (double)pk[PK_W * RTC_WAVE]; };
     auto set_w = [&](double v) {
-        if (SIDE)
+        if (REGS)
+            reg_w = v;
+        else if (SIDE)
             side[3] = v;
         else
             pk[PK_W * RTC_WAVE] = v;
     };
-    auto get_kr = [&]() { return SIDE ? side[4] : (double)pk[PK_KR * RTC_WAVE]; };
+    auto get_kr = [&]() { return REGS ? reg_kr : SIDE ? side[4] : (double)pk[PK_KR * RTC_WAVE]; };
     auto set_kr = [&](double v) {
-        if (SIDE)
+        if (REGS)
+            reg_kr = v;
+        else if (SIDE)
             side[4] = v;
         else
             pk[PK_KR * RTC_WAVE] = v;
@@ -1442,7 +1520,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                 const DPrim p = s.prims[T.prim];
                 __builtin_amdgcn_sched_barrier(0);
                 h_mat = p.material;
-                const double m_transparency = s.materials[h_mat].transparency;
+                const double m_transparency = RTC_MAT_F64(h_mat, 8, transparency);
                 // Intersection::prepare_computations, intersection.rs:123-148
                 h_prim = T.prim;
                 const V3 h_point = ray.o + ray.d * T.lim;
@@ -1468,9 +1546,9 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         SUB_END(ST_PRIMARY);
         if (T.mode == MODE_CLOSEST) {
         } else if (T.mode == MODE_CONTAINER) {
-            const double ri_hit = s.materials[h_mat].refractive_index;
+            const double ri_hit = RTC_MAT_F64(h_mat, 9, refractive_index);
             const double ri_other =
-                (T.c_best_prim >= 0) ? s.materials[s.prims[T.c_best_prim].material].refractive_index : 1.;
+                (T.c_best_prim >= 0) ? RTC_MAT_F64(s.prims[T.c_best_prim].material, 9, refractive_index) : 1.;
             double n1, n2;
             if (T.c_hit_open) {
                 // the hit primitive leaves: n1 = last of (others + hit), n2 = last of the others
@@ -1488,8 +1566,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
             // this way a free lane can start on the next link while this one still lights the hit.  (The containers pass
             // ran because remaining > 0 and the material is transparent; ring order and arithmetic are unchanged.)
             {
-                const DMaterial &m = s.materials[h_mat];
-                const double m_refl = m.reflectivity, m_transp = m.transparency;
+                const double m_refl = RTC_MAT_F64(h_mat, 7, reflectivity), m_transp = RTC_MAT_F64(h_mat, 8, transparency);
                 const V3 h_normal = unpark3(pk, PK_NORMAL);
                 const V3 h_eye = unpark3(pk, PK_EYE);
                 double kr = 1., kt = 1.;
@@ -1545,7 +1622,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         for (;;) {
             if (need_setup) {
                 need_setup = false;
-                const DLight &lt = s.lights[li];
+                const auto &lt = RTC_LOAD_LIGHT(li);
                 const int lt_area = lt.is_area;
                 V3 lp = ld3(lt.position);
                 const V3 lt_pos = lp;
@@ -1576,11 +1653,11 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                 // World::is_shadowed (world.rs:78-91): only the NEAREST positive hit is consulted (Q5); when every
                 // material casts shadows that equals "some hit has 0 < t < distance" (any-hit early exit).
                 const bool shadowed = !behind && T.prim >= 0 &&
-                                      (s.all_cast_shadow || s.materials[s.prims[T.prim].material].casts_shadow != 0);
-                const DLight &lt = s.lights[li];
+                                      (s.all_cast_shadow || RTC_MAT_CASTS(s.prims[T.prim].material));
+                const auto &lt = RTC_LOAD_LIGHT(li);
                 // everything this block and shade_hit's tail will read of the light and the material is requested here
                 // in one go (one round trip; as separate look-ups behind each branch it was five)
-                const DMaterial m = s.materials[h_mat];
+                const DMaterial m = RTC_LOAD_MATERIAL(h_mat);
                 const int lt_area = lt.is_area;
                 const unsigned lt_usteps = lt.usteps, lt_vsteps = lt.vsteps, lt_samples = lt.samples;
                 const V3 lt_pos = ld3(lt.position), lt_int = ld3(lt.intensity);

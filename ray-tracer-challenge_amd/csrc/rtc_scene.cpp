@@ -421,6 +421,7 @@ int Scene::flatten() {
         const DCsgRoot &root = csg_roots[r];
         DPrim p{};
         p.type = PT_CSG;
+        p.material = -1;  // (the tree has no material of its own: its leaves weigh the tiles in build_tile_order)
         p.tri = (int32_t)r;
         p.own_xform = -1;
         p.minimum = -INF, p.maximum = INF;

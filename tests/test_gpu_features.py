@@ -257,6 +257,37 @@ def test_one_process_two_replicas_assemble_the_same_canvas():
         assert st["primary_rays"] == (cam.hsize - 1) * (cam.vsize - 1)  # counters are summed over the replicas
 
 
+def test_alternating_shares_on_a_side_stream_keep_their_own_tile_order():
+    # rtc_render_device is asynchronous on the caller's stream; every share of a frame brings a tile order of
+    # its own, and a launch that is still in flight on a non-blocking stream must keep reading ITS order while the next
+    # call (another share) uploads another.  Two shares alternate without a synchronisation in between; every canvas
+    # must be the share's own, bit for bit (exchange = 1: reproducible), as the synchronous rtc_render returns it.
+    import torch
+    world, cam = _glass_scene(512, 384)
+    scene = cam.compile(world, device=0)
+    try:
+        kw = [dict(tile_rows=8, tile_index=r, tile_count=2, exchange=1) for r in range(2)]
+        want = [scene.render(**k) for k in kw]
+        maps = [scene.local_row_map(tile_rows=8, tile_index=r, tile_count=2) for r in range(2)]
+        fresh = cam.compile(world, device=0)  # (its orders have not been built yet: the first launches build them)
+        try:
+            stream = torch.cuda.Stream(device="cuda:0")
+            bufs = [torch.full((len(maps[i % 2]), cam.hsize, 3), float("nan"), dtype=torch.float64, device="cuda:0")
+                    for i in range(8)]
+            torch.cuda.synchronize()
+            for i, buf in enumerate(bufs):
+                fresh.render_device(buf.data_ptr(), stream.cuda_stream, **kw[i % 2])
+            stream.synchronize()
+            fresh.check()
+            for i, buf in enumerate(bufs):
+                got = buf.cpu().numpy()
+                assert np.array_equal(got, want[i % 2][maps[i % 2]]), i
+        finally:
+            fresh.close()
+    finally:
+        scene.close()
+
+
 def test_two_real_gpus_equal_one():
     import torch
     if torch.cuda.device_count() < 2:

@@ -65,6 +65,15 @@ def test_static_scratch_entry_point_equals_render_device_twice_in_a_row():
         assert e.value.code == rtc._native.ERR_OVERFLOW
         scene.render_device_static(buf.data_ptr(), 0, schedule=2)
         scene.check()
+        # "allocates nothing": device memory that is free before a static call is free after it (every kernel variant
+        # used here has been launched above, so no code object is loaded inside the bracket either)
+        for kw in (dict(schedule=2), dict(schedule=1), dict(schedule=2, exchange=1)):
+            torch.cuda.synchronize()
+            free0, _ = torch.cuda.mem_get_info()
+            scene.render_device_static(buf.data_ptr(), 0, **kw)
+            scene.check()
+            free1, _ = torch.cuda.mem_get_info()
+            assert free1 == free0, (kw, free0, free1)
     finally:
         for scene, _ in scenes:
             scene.close()
