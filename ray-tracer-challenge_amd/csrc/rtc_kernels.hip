@@ -565,9 +565,23 @@ DEV bool slab(const F *bmin, const F *bmax, const V3 &inv_d, const V3 &oi, doubl
 // instruction and ONE wave saturates it; these f32 instructions take 2, the two planes of an axis share one
 // v_pk_fma_f32, and max3 / min3 fold three axes at once (tools/micro/valu_rates.hip has the measured rates).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef RTC_SEG_CACHE
+#define RTC_SEG_CACHE 1
+#endif
+#ifndef RTC_SLAB_PERM
+#define RTC_SLAB_PERM 1  // quantised nodes: near / far plane of an axis picked by the ray's sign (v_perm_b32), no min / max
+#endif
 struct SlabRay {
     float ax, ay, az;    // slope per axis
     f32x2 bx, by, bz;    // intercepts of the (low, high) plane of an axis, widened by the error bound
+                         // (RTC_SLAB_PERM, quantised nodes: of the (near, far) plane)
+#if RTC_SLAB_PERM
+    unsigned sx, sy, sz; // v_perm_b32 selectors that pair an axis' (near, far) cell indices by the sign of its slope
+#endif
+#if RTC_SEG_CACHE
+    float hi, lim_lo;    // T.lim as the end of the f32 ray segment, rounded outward / inward: kept up to date where T.lim
+                         // changes (pass start, leaf tests) instead of being formed from the f64 value in every step
+#endif
 };
 DEV void slab_axis(double a64, double b64, double qmax, float &a, f32x2 &b) {
     a = (float)a64;
@@ -598,6 +612,40 @@ DEV bool slab32_q(unsigned d0, unsigned d1, unsigned d2, const SlabRay &R, float
     const f32x2 pz = {(float)(d1 & 0xffffu), (float)(d2 >> 16)};
     return slab32(px, py, pz, R, lo_t, hi_t, tnear);
 }
+#if RTC_SLAB_PERM
+// Quantised nodes, second form.  Which plane of an axis is the near one follows from the sign of the ray's slope alone,
+// and a correctly rounded fma is monotonic in the plane's index, so picking by sign gives exactly what sorting the two
+// products gave: per axis ONE v_perm_b32 pairs (near, far) out of the node's dwords before the conversions, and the six
+// min / max of a box are gone (20 -> 17 instructions).  The intercepts are then those of the (near, far) plane: the error
+// bound goes b - e / b + e whatever the sign.
+DEV void slab_axis_nf(double a64, double b64, double qmax, float &a, f32x2 &b, unsigned &sel, unsigned pos, unsigned neg) {
+    a = (float)a64;
+    const float bc = (float)b64;
+    const float e = ((float)qmax * fabsf(a) + fabsf(bc)) * 0x1p-21f;
+    b.x = bc - e, b.y = bc + e;
+    sel = (a >= 0.f) ? pos : neg;  // the low plane is the near one for a >= 0
+}
+// min.x = d0[15:0], max.x = d1[31:16]; min.y = d0[31:16], max.y = d2[15:0]; min.z = d1[15:0], max.z = d2[31:16]
+DEV bool slab32_qs(unsigned d0, unsigned d1, unsigned d2, const SlabRay &R, float lo_t, float hi_t, float &tnear) {
+    const unsigned qx = __builtin_amdgcn_perm(d1, d0, R.sx);  // near.x | far.x << 16
+    const unsigned qy = __builtin_amdgcn_perm(d2, d0, R.sy);
+    const unsigned qz = __builtin_amdgcn_perm(d2, d1, R.sz);
+    const f32x2 px = {(float)(qx & 0xffffu), (float)(qx >> 16)};
+    const f32x2 py = {(float)(qy & 0xffffu), (float)(qy >> 16)};
+    const f32x2 pz = {(float)(qz & 0xffffu), (float)(qz >> 16)};
+    const f32x2 ax = {R.ax, R.ax}, ay = {R.ay, R.ay}, az = {R.az, R.az};
+    const f32x2 tx = __builtin_elementwise_fma(px, ax, R.bx);
+    const f32x2 ty = __builtin_elementwise_fma(py, ay, R.by);
+    const f32x2 tz = __builtin_elementwise_fma(pz, az, R.bz);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tx.x, ty.x), tz.x), lo_t);
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(tx.y, ty.y), tz.y), hi_t);
+    tnear = tn;
+    return !(tn > tf);
+}
+#define SLABQ slab32_qs
+#else
+#define SLABQ slab32_q
+#endif
 // T.lim (> 0 or +inf) as the end of the f32 ray segment: rounded away from / towards zero
 DEV float f32_above(double x) { return (float)(x * (1. + 0x1p-22)); }
 DEV float f32_below(double x) { return (float)(x * (1. - 0x1p-22)); }
@@ -1095,6 +1143,12 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
     SlabRay slab_ray;  // this pass's ray in the slab test's f32 form (persists with the traversal)
     slab_ray.ax = slab_ray.ay = slab_ray.az = 0.f;
     slab_ray.bx = slab_ray.by = slab_ray.bz = (f32x2){0.f, 0.f};
+#if RTC_SLAB_PERM
+    slab_ray.sx = slab_ray.sy = slab_ray.sz = 0u;
+#endif
+#if RTC_SEG_CACHE
+    slab_ray.hi = slab_ray.lim_lo = 0.f;
+#endif
     // The ray in group space is cached per lane across the leaves of a pass when primitives sit in groups.  The
     // persistent schedule is chosen for glass-heavy scenes, where the 13 registers this costs between passes are
     // worth more than the transform it saves: there the ray is transformed per grouped leaf.
@@ -1252,6 +1306,15 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
 #ifdef RTC_TIMING_ONLY
     unsigned long long sub_stamp = 0;
 #define SUB_BEGIN() do { if (STATS) sub_stamp = __builtin_amdgcn_s_memtime(); } while (0)
+    // lanes that take part in a block of the state machine, and how often the block runs (free counters of this build)
+#define BLOCK_PROBE(cond, idx_lanes, idx_runs)                                                       \
+    do {                                                                                             \
+        if (STATS) {                                                                                 \
+            const unsigned long long m__ = __ballot(cond);                                           \
+            if (m__ && lane == (unsigned)__ffsll((long long)__ballot(true)) - 1u)                    \
+                cnt.c[idx_lanes] += __popcll(m__), cnt.c[idx_runs] += 1;                             \
+        }                                                                                            \
+    } while (0)
 #define SUB_END(idx)                                                         \
     do {                                                                     \
         if (STATS) {                                                         \
@@ -1263,6 +1326,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
 #else
 #define SUB_BEGIN() do { } while (0)
 #define SUB_END(idx) do { } while (0)
+#define BLOCK_PROBE(cond, idx_lanes, idx_runs) do { } while (0)
 #endif
     for (;;) {
         // =====================================================================================
@@ -1509,6 +1573,8 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         bool begin_lights = false, finish = false, next_ray = false;
         double f_refl = 0.;  // the hit material's reflectivity when `finish` is set
         SUB_BEGIN();
+        BLOCK_PROBE(T.mode == MODE_CLOSEST && T.prim >= 0, ST_XFORM, ST_SCHLICK);
+        BLOCK_PROBE(T.mode == MODE_CONTAINER, ST_REFRACT, ST_SHADOW_SKIPPED);
         if (T.mode == MODE_CLOSEST) {
             // World::color_at, world.rs:30-38
             if (T.prim < 0 || s.n_lights == 0) {
@@ -1649,6 +1715,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
             }
             if (!have_result) break;  // a shadow pass starts (or the lane has nothing to do with lights this round)
             have_result = false;
+            BLOCK_PROBE(true, ST_SECONDARY_REF, ST_OVERFLOW);
             {
                 // World::is_shadowed (world.rs:78-91): only the NEAREST positive hit is consulted (Q5); when every
                 // material casts shadows that equals "some hit has 0 < t < distance" (any-hit early exit).
@@ -1756,6 +1823,12 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         asm volatile("" : "=v"(pos), "=v"(end), "=v"(sb), "=v"(cur));
         asm volatile("" : "=v"(slab_ray.ax), "=v"(slab_ray.ay), "=v"(slab_ray.az));
         asm volatile("" : "=v"(slab_ray.bx), "=v"(slab_ray.by), "=v"(slab_ray.bz));
+#if RTC_SLAB_PERM
+        asm volatile("" : "=v"(slab_ray.sx), "=v"(slab_ray.sy), "=v"(slab_ray.sz));
+#endif
+#if RTC_SEG_CACHE
+        asm volatile("" : "=v"(slab_ray.hi), "=v"(slab_ray.lim_lo));
+#endif
         asm volatile("" : "=v"(T.last), "=v"(T.a), "=v"(T.b), "=v"(T.c_best_prim), "=v"(T.c_hit_open));
 #endif
         }  // if (alive)

@@ -29,5 +29,8 @@ for mode in sys.argv[4:]:
             if os.environ.get("RTC_AMD_LIB", "").endswith("timing.so") and st.get("shaded_hits"):
                 span = st["shaded_hits"] - ((~st["light_evals"]) & 0xFFFFFFFFFFFFFFFF)
                 print("  wave lifetimes (100 MHz ticks): kernel span %d, mean wave lifetime %.0f = %.3f of the span" % (span, pt[6] / 3072.0, pt[6] / 3072.0 / max(span, 1)))
+            if os.environ.get("RTC_AMD_LIB", "").endswith("timing.so"):
+                for nm, a, b in (("closest block", "xform_levels", "schlick_evals"), ("containers block", "refract_evals", "shadow_rays_skipped"), ("lighting block", "secondary_rays_reference", "overflow")):
+                    print("  %-16s ran %d times with %.1f lanes" % (nm, st.get(b, 0), st.get(a, 0) / max(st.get(b, 0), 1)))
             for name, r, l in (("start", d[4], d[5]), ("traverse", d[6], d[7]), ("shade", d[8], d[9])):
                 print("  %-9s rounds %d  lanes/round %.1f" % (name, r, l / max(r, 1)))
