@@ -42,6 +42,7 @@ WORKLOADS = {
 PARITY_PIXELS = {"cover_4k": 100_000, "cover_1080p": 100_000, "teapot_4k": 40_000, "reflective_world_1080p": 300_000,
                  "ice_cream_1080p": 300_000, "stress_1080p": 32, "stress_8k": 32, "stress_4k": 32}
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop (FMA) x 2.4 GHz; strict mode cannot use FMA
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak (the slab tests' packed FMA)
 TILE_ROWS = 8
 
 
@@ -224,13 +225,25 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = rays_per_frame * args.steps / elapsed / 1e6
-    achieved_tflops = local_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-    # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc, separate runs)
-    traffic = None
+    # Roofline, in two parts: the reference's own arithmetic runs in f64 on the vector ALU; the BVH box tests
+    # are this build's culling arithmetic and run in f32 (packed FMA), so they are priced against the f32 vector peak.
+    box_flops_local = 12.0 * float(st["box_tests"])
+    fp64_flops_local = local_flops - box_flops_local
+    secs = kernel_ms * 1e-3
+    fp64_tflops = fp64_flops_local / secs / 1e12 if secs > 0 else 0.0
+    f32_tflops = box_flops_local / secs / 1e12 if secs > 0 else 0.0
+    achieved_tflops = local_flops / secs / 1e12 if secs > 0 else 0.0
+    # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc, separate runs): read from
+    # that file, NOT measured in this run
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload if world_size == 1 else "", {}).get("bytes_per_launch")
+            rec = json.load(open(tpath)).get(args.workload if world_size == 1 else "", {})
+            traffic = rec.get("bytes_per_launch")
+            if traffic is not None:
+                traffic_source = "%s (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, separate passes, of tree %s); read from " \
+                                 "profiles/hbm_traffic.json, not measured in this run" % (rec.get("source"), rec.get("commit", "?"))
         except Exception:
             traffic = None
     out = {
@@ -267,17 +280,30 @@ def main():
                            "shaded_hits": frame["shaded_hits"], "container_passes": frame["container_passes"],
                            "algorithmic_flops": frame_flops},
         "roofline": {
-            "bound": "valu_fp64",  # neither hbm nor mfma bounds this path: the scene is cache-resident, nothing is a GEMM
+            # neither hbm nor mfma bounds this path: the scene is cache-resident, nothing is a GEMM.  The headline pair
+            # (achieved / peak / frac) is the reference's f64 arithmetic against the f64 vector peak; the box tests are
+            # reported beside it against the f32 peak, and `frac_time_at_peaks` says what share of the kernel's time the
+            # two parts would take together if each ran at its own peak.
+            "bound": "valu_fp64",
             "kernel": "rtc::k_render",
-            "achieved": achieved_tflops,
+            "achieved": fp64_tflops,
             "peak": FP64_VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s",
-            "frac": achieved_tflops / FP64_VALU_PEAK_TFLOPS,
-            "frac_of_strict_ceiling": achieved_tflops / (FP64_VALU_PEAK_TFLOPS / 2),
+            "frac": fp64_tflops / FP64_VALU_PEAK_TFLOPS,
+            "frac_of_strict_ceiling": fp64_tflops / (FP64_VALU_PEAK_TFLOPS / 2),
+            "fp64_reference_flops": fp64_flops_local,
+            "f32_culling": {"flops": box_flops_local, "achieved": f32_tflops, "peak": FP32_VALU_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": f32_tflops / FP32_VALU_PEAK_TFLOPS,
+                            "what": "BVH box slab tests (12 flops each, SURVEY 8(d)): the build's own arithmetic, f32"},
+            "frac_time_at_peaks": (fp64_flops_local / (FP64_VALU_PEAK_TFLOPS * 1e12) +
+                                   box_flops_local / (FP32_VALU_PEAK_TFLOPS * 1e12)) / secs if secs > 0 else 0.0,
+            # (rounds 1-2 reported every algorithmic flop against the f64 peak: kept for comparison across rounds)
+            "frac_all_flops_at_fp64_peak": achieved_tflops / FP64_VALU_PEAK_TFLOPS,
             "kernel_ms": kernel_ms,
             "kernel_ms_max_over_ranks": kernel_ms_max,
             "algorithmic_flops_per_launch": local_flops,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "hbm_algorithmic_bytes_per_launch": 24.0 * hsize * local_rows,
             "hbm": {"achieved": 24.0 * hsize * local_rows / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
                     "peak": 8000.0, "unit": "GB/s"},
@@ -312,9 +338,12 @@ def main():
             torch.cuda.synchronize(dev)
             ms = a.elapsed_time(b) / reps
             rays = st2["primary_rays"] + st2["shadow_rays"] + st2["secondary_rays"]
+            box2 = 12.0 * float(st2["box_tests"])
             extra[wl] = {"frame_ms": ms, "Mrays_per_s": rays / ms / 1e3, "rays": rays,
                          "tflops": st2["algorithmic_flops"] / ms / 1e9,
-                         "roofline_frac": st2["algorithmic_flops"] / ms / 1e9 / FP64_VALU_PEAK_TFLOPS}
+                         "roofline_frac": (st2["algorithmic_flops"] - box2) / ms / 1e9 / FP64_VALU_PEAK_TFLOPS,
+                         "f32_culling_frac": box2 / ms / 1e9 / FP32_VALU_PEAK_TFLOPS,
+                         "frac_all_flops_at_fp64_peak": st2["algorithmic_flops"] / ms / 1e9 / FP64_VALU_PEAK_TFLOPS}
             # the reference-shaped call (Camera::render -> Canvas): kernel + device-to-host copy of the canvas into the
             # caller's pageable buffer, end to end, second call (the first one allocates the kept buffers)
             host = np.empty((c2.vsize, c2.hsize, 3), dtype=np.float64)

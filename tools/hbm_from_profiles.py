@@ -7,7 +7,13 @@ import os
 import re
 import sys
 
+import subprocess
+
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
+try:  # the tree the profiles were taken of: pass it as the second argument, else the current HEAD
+    commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    commit = "?"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 out = {}
 for path in sorted(glob.glob(os.path.join(root, "profiles", rnd + "_*.txt"))):
@@ -27,6 +33,7 @@ for path in sorted(glob.glob(os.path.join(root, "profiles", rnd + "_*.txt"))):
             "fetch_bytes": vals["FETCH_SIZE"], "write_bytes": vals["WRITE_SIZE"],
             "bytes_per_launch": vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
             "source": "profiles/" + os.path.basename(path),
+            "commit": commit,
             "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB), separate passes, per k_render launch of the timed "
                     "variant; FETCH_SIZE is NOT doubled: the guide's x2 applies to 16 B/lane streaming reads, these are "
                     "scattered 16-64 B record reads (uncalibrated width); Infinity-Cache hits are included in both",
