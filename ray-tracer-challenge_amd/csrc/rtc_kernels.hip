@@ -799,6 +799,13 @@ DEV bool isect_csg(const DScene &s, int tree, const Ray &ray, Trace &T) {
 #ifndef RTC_LDS_STACK
 #define RTC_LDS_STACK 16
 #endif
+#ifndef RTC_ONE_LIGHT_LDS
+#define RTC_ONE_LIGHT_LDS 1
+#endif
+#ifndef RTC_CANVAS_MODE
+#define RTC_CANVAS_MODE 0  // persistent grid, where a pixel's colour is accumulated: 0 = the lane's side line, 1 = in the
+                           // canvas with atomics (A/B, rejected), 2 = in the canvas, plain while one lane owns the pixel
+#endif
 #ifndef RTC_STATIC_REGS
 #define RTC_STATIC_REGS 0  // A/B only (rejected): static schedule keeps colour / weight / Schlick factor in registers
 #endif
@@ -983,6 +990,19 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
     // the ten registers live across the traversal loop cost more than the LDS was worth (cover 4K 3.26 -> 3.67 ms,
     // profiles/r3_ab/r3_ab_regs.txt)
     constexpr bool REGS = !PERSISTENT && RTC_STATIC_REGS;
+    // A/B only (rejected, profiles/r3_ab/r3_ab_canvas.txt): the persistent grid ADDS every hit's share `weight x surface`
+    // to the canvas with a no-return f64 atomic instead of carrying the pixel's colour in the lane's side line.  Same
+    // pixels (one lane's additions reach a pixel in program order), same frame time (995 vs 997 ms) -- and MORE memory
+    // traffic, not less: device-scope atomics are carried out on the memory side and each one is counted (and paid for)
+    // as a write request of its own (WRITE_SIZE 430 -> 517 GB per frame).
+    // Mode 2 (A/B, rejected: 981 vs 972 ms): the pixel's colour is accumulated in the canvas itself -- zeroed when the lane takes the pixel,
+    // `canvas += weight x surface` at every hit as an ordinary load / add / store while one lane owns the pixel (the same
+    // additions in the same order as an accumulator that travels with the lane), and as atomics once the pixel's ray tree
+    // has been split between lanes at the end of the frame (the owner's plain stores are written back before the first
+    // hand-over, see the donors' fence).  A tile row's lanes share canvas lines; the side line was one 64-byte line per
+    // LANE that every hit read, dirtied and -- L2 being what it is under this kernel -- wrote back.
+    constexpr bool CANVAS_ACC = PERSISTENT && RTC_CANVAS_MODE != 0;
+    constexpr bool CANVAS_RMW = PERSISTENT && RTC_CANVAS_MODE == 2;
     __shared__ double parked[((SIDE || REGS) ? PK_COUNT_SIDE : PK_COUNT) * RTC_WAVE];
 #if RTC_LDS_TOP
     // A/B only ("LDS staging"): the first RTC_LDS_TOP nodes of the breadth-first hierarchy -- its
@@ -1081,37 +1101,56 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
     // still to be traced -- can be handed to a free lane at the end of the frame (see "tail" below)
     Pending pend_private[RTC_MAX_DEPTH_STACK];
     // (persistent grid: the ring lives in the work buffer, one 64-byte line per entry, [wave][lane][entry])
+    // (persistent grid: the ring lives in the work buffer, one 64-byte line per entry, [wave][lane][entry])
     Pending *const pend_global =
         (Pending *)((char *)work + RTC_WORK_RING_OFFSET) + ((size_t)blockIdx.x * RTC_WAVE + threadIdx.x) * RTC_LANE_LINES;
-    // the lane's side line behind its ring: colour[3], weight, Schlick factor (SIDE), else their LDS slots
-    double *const side = (double *)(pend_global + RTC_RING_SLOTS);
+    // the lane's side line behind its ring: colour[3], weight, Schlick factor (SIDE), else their LDS slots.  (A/B, round
+    // 3: the same values as [value][lane] arrays per wave, 2.5 KB instead of 64 lines -- slower and MORE write traffic,
+    // 987 vs 971 ms, 318 vs 269 GB: a lane's three colour values then sit in three lines instead of one.)
+    double *const side_base = (double *)(pend_global + RTC_RING_SLOTS);
+#define side(k) side_base[(k)]
     V3 reg_color = mk(0., 0., 0.);
     double reg_w = 0., reg_kr = 0.;
-    auto get_color = [&]() { return REGS ? reg_color : SIDE ? mk(side[0], side[1], side[2]) : unpark3(pk, PK_COLOR); };
+    auto get_color = [&]() { return REGS ? reg_color : SIDE ? mk(side(0), side(1), side(2)) : unpark3(pk, PK_COLOR); };
     auto set_color = [&](V3 v) {
         if (REGS)
             reg_color = v;
         else if (SIDE)
-            side[0] = v.x, side[1] = v.y, side[2] = v.z;
+            side(0) = v.x, side(1) = v.y, side(2) = v.z;
         else
             park3(pk, PK_COLOR, v);
     };
-    auto get_w = [&]() { return REGS ? reg_w : SIDE ? side[3] : (double)pk[PK_W * RTC_WAVE]; };
+    // Persistent grid with ONE light (wave-uniform): the sum over the lights never waits in LDS -- Material::lighting and
+    // shade_hit's tail run in the same visit of the state machine -- so its three slots are free, and the ray's weight and
+    // the hit's Schlick factor live there instead of in the side line: one global line per lane less to read, dirty and
+    // write back at every hit (the stress scene has one light; WRITE_SIZE 430 -> see profiles/r3_stress_4k.txt).
+    const bool lds_w = SIDE && RTC_ONE_LIGHT_LDS && s.n_lights == 1;
+    auto get_w = [&]() {
+        return REGS ? reg_w : SIDE ? (lds_w ? (double)pk[(PK_SURFACE + 0) * RTC_WAVE] : side(3)) : (double)pk[PK_W * RTC_WAVE];
+    };
     auto set_w = [&](double v) {
         if (REGS)
             reg_w = v;
-        else if (SIDE)
-            side[3] = v;
-        else
+        else if (SIDE) {
+            if (lds_w)
+                pk[(PK_SURFACE + 0) * RTC_WAVE] = v;
+            else
+                side(3) = v;
+        } else
             pk[PK_W * RTC_WAVE] = v;
     };
-    auto get_kr = [&]() { return REGS ? reg_kr : SIDE ? side[4] : (double)pk[PK_KR * RTC_WAVE]; };
+    auto get_kr = [&]() {
+        return REGS ? reg_kr : SIDE ? (lds_w ? (double)pk[(PK_SURFACE + 1) * RTC_WAVE] : side(4)) : (double)pk[PK_KR * RTC_WAVE];
+    };
     auto set_kr = [&](double v) {
         if (REGS)
             reg_kr = v;
-        else if (SIDE)
-            side[4] = v;
-        else
+        else if (SIDE) {
+            if (lds_w)
+                pk[(PK_SURFACE + 1) * RTC_WAVE] = v;
+            else
+                side(4) = v;
+        } else
             pk[PK_KR * RTC_WAVE] = v;
     };
 #define pend_at(i) (*((PERSISTENT && RTC_RING_GLOBAL) ? &pend_global[i] : &pend_private[i]))
@@ -1166,6 +1205,12 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
     const const_leaf_ptr lin = (const_leaf_ptr)(use_bvh ? s.leaves : s.leaves_all);
     const int n_lin = use_bvh ? s.n_unbounded : s.n_prims;
 
+    auto pixel_ptr = [&]() {
+        const unsigned tile = prm.tile_order ? n_tiles - 1u - (pix >> 6) : (pix >> 6), q = pix & 63u;
+        const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
+        const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
+        return out + ((size_t)l * s.hsize + x) * 3u;
+    };
     // binds this lane to pixel `pix`: primary ray and a fresh path state, or a black pixel (Q1 / tile padding)
     auto init_pixel = [&]() {
         const unsigned tile = prm.tile_order ? n_tiles - 1u - (pix >> 6) : (pix >> 6), q = pix & 63u;
@@ -1189,7 +1234,12 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                 const V3 pixel = xf_point(cam->inv, mk(wx, wy, -1.));
                 ray.o = xf_point(cam->inv, mk(0., 0., 0.));
                 ray.d = normalize(pixel - ray.o);
-                set_color(mk(0., 0., 0.));
+                if (CANVAS_ACC) {
+                    double *px = out + ((size_t)l * s.hsize + x) * 3u;
+                    px[0] = 0., px[1] = 0., px[2] = 0.;  // the accumulator of this pixel
+                } else {
+                    set_color(mk(0., 0., 0.));
+                }
                 set_w(1.);
                 mult = 1.;
                 remaining = (int)prm.depth;
@@ -1208,6 +1258,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
     };
     // the pixel is finished: Canvas::write_pixel (camera.rs:87-91)
     auto write_pixel = [&]() {
+        if (CANVAS_ACC) return;  // (every hit's share is in the canvas already)
         const unsigned tile = prm.tile_order ? n_tiles - 1u - (pix >> 6) : (pix >> 6), q = pix & 63u;
         const unsigned x = (tile % prm.tiles_x) * 8u + (q & 7u);
         const unsigned l = (tile / prm.tiles_x) * 8u + (q >> 3);
@@ -1235,7 +1286,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         shared = true;
         alive = true;
         ray.o = qo, ray.d = qd, remaining = qrem;
-        set_color(mk(0., 0., 0.));
+        if (!CANVAS_ACC) set_color(mk(0., 0., 0.));
         set_w(qw);
         if (STATS) mult = qmult;
         sp = 0, pbase = 0;
@@ -1404,7 +1455,9 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                             pbase = (pbase + 1) & (RTC_MAX_DEPTH_STACK - 1);
                             sp--;
                             if (!shared) {
-                                zero_pixel();
+                                if (!CANVAS_ACC) zero_pixel();
+                                // (what this lane has stored into the pixel so far is in memory before anyone adds to it)
+                                if (CANVAS_RMW) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                                 shared = true;
                             }
                         }
@@ -1475,7 +1528,9 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                             pbase = (pbase + 1) & (RTC_MAX_DEPTH_STACK - 1);
                             sp--;
                             if (!shared) {
-                                zero_pixel();
+                                if (!CANVAS_ACC) zero_pixel();
+                                // (what this lane has stored into the pixel so far is in memory before anyone adds to it)
+                                if (CANVAS_RMW) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                                 shared = true;
                             }
                             unsigned long long *it = box + rank * RTC_MBOX_ITEM_U64;
@@ -1571,7 +1626,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         // state machine
         // =====================================================================================
         bool begin_lights = false, finish = false, next_ray = false;
-        double f_refl = 0.;  // the hit material's reflectivity when `finish` is set
+        double f_refl = 0., f_transp = 0.;  // the hit material's reflectivity / transparency when `finish` is set
         SUB_BEGIN();
         BLOCK_PROBE(T.mode == MODE_CLOSEST && T.prim >= 0, ST_XFORM, ST_SCHLICK);
         BLOCK_PROBE(T.mode == MODE_CONTAINER, ST_REFRACT, ST_SHADOW_SKIPPED);
@@ -1596,7 +1651,6 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                 park3(pk, PK_POINT, h_point);
                 park3(pk, PK_EYE, h_eye);
                 park3(pk, PK_NORMAL, n);
-                set_kr(1.);
                 CNT(ST_SHADED, 1);
                 if (remaining > 0 && m_transparency != 0.) {
                     // containers loop (intersection.rs:150-179) in streaming form: second pass over the same
@@ -1642,7 +1696,9 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                     kr = r;
                     kt = 1. - r;
                 }
-                set_kr(kr);  // reflected_color's share, used by shade_hit's tail below
+                // reflected_color's share, used by shade_hit's tail below -- stored only where it is not 1: the tail
+                // asks for it under the same condition (containers pass ran, material reflective and transparent)
+                if (m_refl > 0. && m_transp > 0.) set_kr(kr);
                 const double n_ratio = n1 / n2;
                 const double cos_i = dot(h_eye, h_normal);
                 const double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
@@ -1681,6 +1737,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         // reach the pixel; such a sample goes straight back into the loop as a result (bit-identical colours, and
         // for the mirror / glass spheres of the stress scene about half of all shadow passes).
         bool have_result = T.mode == MODE_SHADOW, need_setup = begin_lights, behind = false;
+        V3 surface_now = mk(0., 0., 0.);  // one light: Material::lighting's result on its way to shade_hit's tail
         if (begin_lights) li = 0, su = sv = 0, unshadowed = 0;
         // (the set-up comes first in program order: a lane whose light is behind the surface falls through into the SAME
         // execution of the lighting block that serves the lanes arriving with a shadow pass's result)
@@ -1752,7 +1809,10 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                 const V3 c = lighting(m, col, lightv, lt_int, unpark3(pk, PK_EYE), unpark3(pk, PK_NORMAL), inten);
                 CNT(ST_LIGHT, 1);
                 SUB_END(ST_PRIM0 + 1);  // (timing build: Material::lighting)
-                park3(pk, PK_SURFACE, (li == 0) ? c : unpark3(pk, PK_SURFACE) + c);  // world.rs:70 left fold
+                if (lds_w)
+                    surface_now = c;  // (the only light: shade_hit's tail follows in this visit)
+                else
+                    park3(pk, PK_SURFACE, (li == 0) ? c : unpark3(pk, PK_SURFACE) + c);  // world.rs:70 left fold
                 li++;
                 su = sv = 0;
                 unshadowed = 0;
@@ -1760,7 +1820,7 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                 if (li < s.n_lights)
                     need_setup = true;
                 else
-                    finish = true, f_refl = m.reflectivity;
+                    finish = true, f_refl = m.reflectivity, f_transp = m.transparency;
             }
             if (!need_setup) break;
         }
@@ -1769,7 +1829,19 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
             // World::shade_hit (world.rs:42-76).  The reference evaluates reflected_color/refracted_color inside
             // the per-light loop (Q3), i.e. adds them n_lights times: that factor goes into the child's weight.
             const double w = get_w();
-            set_color(get_color() + unpark3(pk, PK_SURFACE) * w);
+            if (CANVAS_ACC) {
+                const V3 part = (lds_w ? surface_now : unpark3(pk, PK_SURFACE)) * w;
+                double *px = pixel_ptr();
+                if (CANVAS_RMW && !shared) {
+                    px[0] = px[0] + part.x, px[1] = px[1] + part.y, px[2] = px[2] + part.z;
+                } else {  // (no-return atomics: nothing to wait for)
+                    __hip_atomic_fetch_add(px + 0, part.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(px + 1, part.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(px + 2, part.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                set_color(get_color() + (lds_w ? surface_now : unpark3(pk, PK_SURFACE)) * w);
+            }
             next_ray = true;
             if (remaining > 0 && f_refl != 0.) {
                 // reflected_color, world.rs:93-106 (the refracted ray, if any, already waits in the ring)
@@ -1777,7 +1849,10 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                 const V3 h_eye = unpark3(pk, PK_EYE);
                 ray.o = unpark3(pk, PK_POINT) + h_normal * RTC_EPS;  // over_point
                 ray.d = reflect(-h_eye, h_normal);
-                set_w(w * (nl * (f_refl * get_kr())));
+                // (the Schlick factor exists where the containers block stored it: that block ran iff remaining > 0 and
+                // the material is transparent, and stored iff it is reflective as well; everywhere else it is 1)
+                const double kr = (f_transp != 0. && f_refl > 0. && f_transp > 0.) ? get_kr() : 1.;
+                set_w(w * (nl * (f_refl * kr)));
                 remaining -= 1;
                 if (STATS) mult = mult * nl;
                 next_ray = false;
@@ -1808,7 +1883,11 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
         if (rays > (int)prm.max_rays) {
             CNT(ST_OVERFLOW, 1);
             flag_overflow();
-            set_color(mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.));
+            if (CANVAS_ACC)
+                __hip_atomic_fetch_add(pixel_ptr(), __longlong_as_double(0x7ff8000000000000LL), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            else
+                set_color(mk(__longlong_as_double(0x7ff8000000000000LL), 0., 0.));
             alive = false;
         }
         SUB_END(ST_BOX);
