@@ -505,16 +505,18 @@ static int launch_on(Scene &s, DeviceReplica &r, const DRenderParams &p, const r
         if (have) pp.tile_perm = have->d_perm, n_heavy = have->n_heavy;
     }
     if (!p.persistent && p.share != 0u && pp.tile_perm && n_heavy > 0) {
-        // Parts per heavy tile.  Splitting shortens a heavy tile's critical path (cover.yaml at 1080p, the band through
-        // the glass sphere alone: 1.6 ms whole, 0.5 ms in quarters) and costs instructions (the lanes of a part sit in
-        // different blocks of the state machine: about twice the wave-cycles in quarters), so it pays while the device
-        // has room.  Calibrated on cover.yaml and reflective_world.yaml from 320x180 to 3840x2160
-        // (profiles/r3_ab/r3_parts_ladder.txt; "heavy" is generous -- projected bounding boxes): quarters up to a third
-        // of the resident waves' worth of heavy tiles, halves up to twice the resident waves, whole tiles beyond.
+        // Parts per heavy tile ("heavy": the projected bounds of something reflective or transparent touch it).  Splitting
+        // shortens a tile's critical path (cover.yaml at 1080p, the band through the glass sphere alone: 1.6 ms whole,
+        // 0.5 ms in quarters) and costs instructions (the lanes of a part sit in different blocks of the state machine:
+        // about twice the wave-cycles in quarters), so it pays while the device has room.  Calibrated on cover.yaml and
+        // reflective_world.yaml from 320x180 to 3840x2160 (profiles/r3_ab/r3_parts_ladder_heavy1.txt; with "heavy" =
+        // transparent only, r3_parts_ladder_heavy4.txt, small frames were 10-20 % slower): quarters up to twice the
+        // resident waves' worth of heavy tiles, halves up to ten times, whole tiles beyond.  The two scenes disagree by
+        // 10-20 % on where the lines should be (cover likes quarters longer); these minimise the worst case.
         // RTC_TILE_SPLIT = 1 / 2 / 4 forces the number of parts.
         const int forced = getenv("RTC_TILE_SPLIT") ? atoi(getenv("RTC_TILE_SPLIT")) : 0;  // (read per launch: an A/B knob)
         const uint64_t slots = (uint64_t)r.n_cu * 4u * RTC_MIN_WAVES;
-        uint32_t shift = (uint64_t)n_heavy * 3u <= slots ? 2u : ((uint64_t)n_heavy <= 2u * slots ? 1u : 0u);
+        uint32_t shift = (uint64_t)n_heavy <= 2u * slots ? 2u : ((uint64_t)n_heavy <= 10u * slots ? 1u : 0u);
         if (forced == 1) shift = 0;
         if (forced == 2) shift = 1;
         if (forced == 4) shift = 2;

@@ -858,7 +858,9 @@ void Scene::build_tile_order() {
     for (uint32_t t = 0; t < tx * ty; t++) tile_perm[t] = t;
     std::stable_sort(tile_perm.begin(), tile_perm.end(), [&](uint32_t a, uint32_t c) { return score[a] > score[c]; });
     tile_score.swap(score);
-    for (uint32_t t : tile_perm) n_heavy_tiles += tile_score[t] >= RTC_HEAVY_TILE_SCORE ? 1u : 0u;  // (they come first)
+    static const int heavy_env = getenv("RTC_HEAVY_SCORE") ? atoi(getenv("RTC_HEAVY_SCORE")) : 0;  // (A/B knob)
+    const int32_t heavy = heavy_env > 0 ? heavy_env : RTC_HEAVY_TILE_SCORE;
+    for (uint32_t t : tile_perm) n_heavy_tiles += tile_score[t] >= heavy ? 1u : 0u;  // (they come first)
 }
 
 // ---------------------------------------------------------------------------------------------

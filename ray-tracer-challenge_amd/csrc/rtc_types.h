@@ -258,7 +258,7 @@ struct DScene {
 // refracted rays from the first round on, so the tile's critical path is nearer the depth of its ray trees than their
 // size.  The heavy tiles are the first DRenderParams::n_heavy entries of the (sorted) tile list; the launcher picks the
 // number of parts by how many such tiles there are for the device's resident waves (rtc_api.cpp, launch_on).
-#define RTC_HEAVY_TILE_SCORE 4  // Scene::build_tile_order: weight of one transparent primitive
+#define RTC_HEAVY_TILE_SCORE 1  // Scene::build_tile_order: a tile that shows anything reflective (1) or transparent (4)
 #ifndef RTC_MIN_WAVES
 #define RTC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (static schedule)
 #endif
