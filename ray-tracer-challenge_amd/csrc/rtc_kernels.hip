@@ -1989,7 +1989,9 @@ static void launch_variant(const DScene &scene, DRenderParams &params, double *d
     // (best when some pixels grow ray trees thousands of rays deep)
     if (params.persistent) {
         // occupancy is a property of the code object (queried once per variant); the CU count is this device's
-        static const unsigned per_cu = resident_waves_per_cu(k_render<STATS, GROUPS, PATTERNS, true, QNODES>);
+        static const unsigned per_cu_env = getenv("RTC_GRID_PER_CU") ? (unsigned)atoi(getenv("RTC_GRID_PER_CU")) : 0u;  // (A/B)
+        static const unsigned per_cu_occ = resident_waves_per_cu(k_render<STATS, GROUPS, PATTERNS, true, QNODES>);
+        const unsigned per_cu = per_cu_env ? per_cu_env : per_cu_occ;
         // (the work buffer holds a mailbox and a ring of waiting rays per wave of the grid: RTC_MAX_WAVES of them)
         const unsigned cap = (RTC_RING_GLOBAL && per_cu * n_cu > RTC_MAX_WAVES) ? RTC_MAX_WAVES : per_cu * n_cu;
         const unsigned waves = tiles < cap ? tiles : cap;
