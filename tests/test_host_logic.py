@@ -155,3 +155,15 @@ def test_csg_call_order_and_flattening():
     it = N.ItemInfo()
     assert L.rtc_scene_get_item(h, 0, C.byref(it)) == N.OK and it.kind == 3 and it.shape_type == N.CSG_DIFFERENCE
     L.rtc_scene_destroy(h)
+
+
+def test_heavy_tiles_are_the_ones_that_show_reflective_or_transparent_objects():
+    # the static schedule's tile order: tiles touched by the projected bounds of something
+    # reflective or transparent are "heavy" -- rendered first and, where the device has room, in parts
+    tiles = lambda w, h: ((w + 7) // 8) * ((h + 7) // 8)
+    i = _info("cover", 320, 180)          # a glass sphere among 17 slightly reflective cubes
+    assert 0 < i["n_heavy_tiles"] < tiles(320, 180)
+    j = _info("cover", 640, 360)
+    assert 3 * i["n_heavy_tiles"] < j["n_heavy_tiles"] < 5 * i["n_heavy_tiles"]  # an area: ~4x at twice the resolution
+    assert _info("ice_cream", 320, 180)["n_heavy_tiles"] == 0   # opaque cone + sphere
+    assert _info("teapot", 320, 160)["n_heavy_tiles"] == 0      # opaque mesh, matte planes (unbounded: never weighed)
