@@ -366,10 +366,20 @@ typedef struct {
 } xs_t;
 
 typedef struct {
-    uint64_t primary, shadow, secondary;
+    uint64_t primary, shadow, secondary, diverged;
 } counters_t;
 
 static __thread counters_t *tl_counters;
+
+/* Nesting guard of color_at (not in the reference).  refracted_color keeps the bounce budget (world.rs:142, Q2), so a
+ * ray that is caught between refracting surfaces -- a glass double cone around its apex, a glass smooth triangle whose
+ * interpolated normal disagrees with its face -- recurses without end: the reference overflows its stack there (a
+ * rayon worker has 2 MB) and aborts.  The oracle stops at ORC_MAX_NESTING nested color_at calls instead, marks the
+ * pixel as DIVERGED (NaN in the canvas, counted in orc_stats.diverged_pixels) and carries on with the next pixel: a
+ * scene with such pixels has no reference image, parity tests must not use it. */
+#define ORC_MAX_NESTING 2048
+#define ORC_WORKER_STACK ((size_t)64 << 20)
+static __thread int tl_nesting, tl_diverged;
 
 static void xs_init(xs_t *l) {
     l->data = l->inl;
@@ -1126,6 +1136,7 @@ static double comps_schlick(const comps_t *c) {
 /* ------------------------------------------------------------------ world.rs */
 
 static v3 world_color_at(const orc_world *w, const ray_t *ray, int remaining);
+static ray_t camera_ray_for_pixel_fwd(const orc_world *w, uint32_t px, uint32_t py);
 
 /* world.rs:78-91 */
 static int world_is_shadowed(const orc_world *w, v3 point, v3 light_position) {
@@ -1224,22 +1235,48 @@ static v3 world_shade_hit(const orc_world *w, const comps_t *c, int remaining) {
 /* world.rs:30-38 */
 static v3 world_color_at(const orc_world *w, const ray_t *ray, int remaining) {
     xs_t xs;
+    v3 color = v3_new(0., 0., 0.);
+    if (tl_diverged) return color; /* unwinding a diverged pixel: no further work */
+    if (tl_nesting >= ORC_MAX_NESTING) {
+        tl_diverged = 1;
+        return color;
+    }
     xs_init(&xs);
     world_intersect(w, ray, &xs);
     int h = hit_index(xs.data, xs.n);
-    v3 color = v3_new(0., 0., 0.);
     if (h >= 0) {
         comps_t c = prepare_computations(w, &xs.data[h], ray, xs.data, xs.n);
         xs_free(&xs); /* the list is not needed below; frees memory before recursing */
-        return world_shade_hit(w, &c, remaining);
+        tl_nesting++;
+        color = world_shade_hit(w, &c, remaining);
+        tl_nesting--;
+        return color;
     }
     xs_free(&xs);
     return color;
 }
 
+/* one pixel of Camera::render (camera.rs:78-84) under the nesting guard */
+static v3 pixel_color(const orc_world *w, uint32_t x, uint32_t y, counters_t *counters) {
+    ray_t ray = camera_ray_for_pixel_fwd(w, x, y);
+    counters->primary++;
+    tl_nesting = 0, tl_diverged = 0;
+    v3 c = world_color_at(w, &ray, w->depth_override ? w->depth_override - 1 : 5); /* camera.rs:80 */
+    if (tl_diverged) {
+        counters->diverged++;
+        c = v3_new(NAN, NAN, NAN);
+        tl_diverged = 0;
+    }
+    return c;
+}
+
 /* ------------------------------------------------------------------ camera.rs */
 
 /* camera.rs:41-59 */
+static ray_t camera_ray_for_pixel(const orc_world *w, uint32_t px, uint32_t py);
+static ray_t camera_ray_for_pixel_fwd(const orc_world *w, uint32_t px, uint32_t py) {
+    return camera_ray_for_pixel(w, px, py);
+}
 static ray_t camera_ray_for_pixel(const orc_world *w, uint32_t px, uint32_t py) {
     double x_offset = ((double)px + 0.5) * w->pixel_size;
     double y_offset = ((double)py + 0.5) * w->pixel_size;
@@ -1285,9 +1322,7 @@ static void *render_worker(void *arg) {
         if (y >= j->row_end) break;
         /* camera.rs:78: x in 0..hsize-1 (Q1) */
         for (uint32_t x = 0; x + 1 < w->hsize; x += j->col_step) {
-            ray_t ray = camera_ray_for_pixel(w, x, y);
-            j->counters.primary++;
-            v3 c = world_color_at(w, &ray, w->depth_override ? w->depth_override - 1 : 5); /* camera.rs:80 */
+            v3 c = pixel_color(w, x, y, &j->counters);
             double *px = j->out + ((size_t)y * w->hsize + x) * 3;
             px[0] = c.x, px[1] = c.y, px[2] = c.z;
         }
@@ -1311,6 +1346,9 @@ int orc_render_subset(orc_world *w, int nthreads, uint32_t row_begin, uint32_t r
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
     pthread_t th[256];
     job_t jobs[256];
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, ORC_WORKER_STACK);
     for (int i = 0; i < nthreads; i++) {
         memset(&jobs[i], 0, sizeof(job_t));
         jobs[i].w = w;
@@ -1321,20 +1359,23 @@ int orc_render_subset(orc_world *w, int nthreads, uint32_t row_begin, uint32_t r
         jobs[i].col_step = col_step;
         jobs[i].next_row = &next_row;
         jobs[i].mu = &mu;
-        pthread_create(&th[i], NULL, render_worker, &jobs[i]);
+        pthread_create(&th[i], &attr, render_worker, &jobs[i]);
     }
-    counters_t total = {0, 0, 0};
+    pthread_attr_destroy(&attr);
+    counters_t total = {0, 0, 0, 0};
     for (int i = 0; i < nthreads; i++) {
         pthread_join(th[i], NULL);
         total.primary += jobs[i].counters.primary;
         total.shadow += jobs[i].counters.shadow;
         total.secondary += jobs[i].counters.secondary;
+        total.diverged += jobs[i].counters.diverged;
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (stats) {
         stats->primary_rays = total.primary;
         stats->shadow_rays = total.shadow;
         stats->secondary_rays = total.secondary;
+        stats->diverged_pixels = total.diverged;
         stats->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     }
     return ORC_OK;
@@ -1367,9 +1408,7 @@ static void *pixels_worker(void *arg) {
         double *px = j->out + 3 * i;
         px[0] = px[1] = px[2] = 0.;
         if (x + 1 >= w->hsize || y + 1 >= w->vsize) continue; /* camera.rs:72,78 (Q1) */
-        ray_t ray = camera_ray_for_pixel(w, x, y);
-        j->counters.primary++;
-        v3 c = world_color_at(w, &ray, w->depth_override ? w->depth_override - 1 : 5); /* camera.rs:80 */
+        v3 c = pixel_color(w, x, y, &j->counters);
         px[0] = c.x, px[1] = c.y, px[2] = c.z;
     }
     tl_counters = NULL;
@@ -1387,24 +1426,30 @@ int orc_render_pixels(orc_world *w, int nthreads, size_t n, const uint32_t *xy, 
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
     pthread_t th[256];
     pjob_t jobs[256];
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, ORC_WORKER_STACK);
     for (int i = 0; i < nthreads; i++) {
         memset(&jobs[i], 0, sizeof(pjob_t));
         jobs[i].w = w, jobs[i].xy = xy, jobs[i].out = rgb_out, jobs[i].n = n;
         jobs[i].next = &next, jobs[i].mu = &mu;
-        pthread_create(&th[i], NULL, pixels_worker, &jobs[i]);
+        pthread_create(&th[i], &attr, pixels_worker, &jobs[i]);
     }
-    counters_t total = {0, 0, 0};
+    pthread_attr_destroy(&attr);
+    counters_t total = {0, 0, 0, 0};
     for (int i = 0; i < nthreads; i++) {
         pthread_join(th[i], NULL);
         total.primary += jobs[i].counters.primary;
         total.shadow += jobs[i].counters.shadow;
         total.secondary += jobs[i].counters.secondary;
+        total.diverged += jobs[i].counters.diverged;
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (stats) {
         stats->primary_rays = total.primary;
         stats->shadow_rays = total.shadow;
         stats->secondary_rays = total.secondary;
+        stats->diverged_pixels = total.diverged;
         stats->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     }
     return ORC_OK;
@@ -1418,6 +1463,12 @@ int orc_render(orc_world *w, int nthreads, double *rgb_out, orc_stats *stats) {
 /* ------------------------------------------------------------------ unit-level entry points */
 
 static v3 in3(const double p[3]) { return v3_new(p[0], p[1], p[2]); }
+/* a unit-level call whose ray tree tripped the nesting guard answers NaN, like a pixel */
+static v3 unit_result(v3 c) {
+    if (tl_diverged) c = v3_new(NAN, NAN, NAN);
+    tl_diverged = 0;
+    return c;
+}
 static void out3(v3 a, double o[3]) { o[0] = a.x, o[1] = a.y, o[2] = a.z; }
 
 int orc_ray_for_pixel(orc_world *w, uint32_t px, uint32_t py, double origin[3], double direction[3]) {
@@ -1504,7 +1555,8 @@ int orc_shape_includes(orc_world *w, int shape, int object) {
 int orc_color_at(orc_world *w, const double origin[3], const double direction[3], int remaining, double rgb[3]) {
     if (!world_check_invertible(w)) return ORC_ERR_NON_INVERTIBLE;
     ray_t r = {in3(origin), in3(direction)};
-    out3(world_color_at(w, &r, remaining), rgb);
+    tl_nesting = 0, tl_diverged = 0;
+    out3(unit_result(world_color_at(w, &r, remaining)), rgb);
     return ORC_OK;
 }
 int orc_is_shadowed(orc_world *w, const double point[3], const double light_position[3], int *out) {
@@ -1607,17 +1659,20 @@ int orc_prepare_computations(orc_world *w, const double origin[3], const double 
 }
 int orc_shade_hit(orc_world *w, const double *comps, int remaining, double rgb[3]) {
     comps_t c = comps_unpack(comps);
-    out3(world_shade_hit(w, &c, remaining), rgb);
+    tl_nesting = 0, tl_diverged = 0;
+    out3(unit_result(world_shade_hit(w, &c, remaining)), rgb);
     return ORC_OK;
 }
 int orc_reflected_color(orc_world *w, const double *comps, int remaining, double rgb[3]) {
     comps_t c = comps_unpack(comps);
-    out3(world_reflected_color(w, &c, remaining), rgb);
+    tl_nesting = 0, tl_diverged = 0;
+    out3(unit_result(world_reflected_color(w, &c, remaining)), rgb);
     return ORC_OK;
 }
 int orc_refracted_color(orc_world *w, const double *comps, int remaining, double rgb[3]) {
     comps_t c = comps_unpack(comps);
-    out3(world_refracted_color(w, &c, remaining), rgb);
+    tl_nesting = 0, tl_diverged = 0;
+    out3(unit_result(world_refracted_color(w, &c, remaining)), rgb);
     return ORC_OK;
 }
 double orc_schlick(const double *comps) {

@@ -71,6 +71,8 @@ typedef struct orc_stats {
     uint64_t shadow_rays;
     uint64_t secondary_rays; /* reference-equivalent count: subtrees re-traced once per light */
     double seconds;
+    uint64_t diverged_pixels; /* pixels whose ray tree nested deeper than the oracle's guard (rtc_oracle.c ORC_MAX_NESTING):
+                                 the reference overflows its stack on them; they are NaN in the canvas */
 } orc_stats;
 
 /* ---- matrix / transform helpers (matrix.rs, transformation.rs); all 4x4 row-major ---- */

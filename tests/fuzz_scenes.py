@@ -1,0 +1,164 @@
+"""Seeded random scenes for the fuzz parity tests (tests/test_gpu_fuzz.py on the GPU, tests/test_oracle_guard.py on
+the CPU): every shape kind, nested groups, Csg trees, patterns, glass and mirrors, point and area lights, random
+transforms (rotations, non-uniform scales, shears) and cameras.  Deterministic per seed (numpy Generator, PCG64)."""
+import math
+
+import numpy as np
+
+from scene_feed import rtc
+
+M = rtc.Matrix
+
+
+def _colour(rng, lo=0.05, hi=1.0):
+    return tuple(float(v) for v in rng.uniform(lo, hi, 3))
+
+
+def _transform(rng, spread=3.0, lift=True):
+    t = M.scaling(*[float(v) for v in rng.uniform(0.35, 1.3, 3)])
+    if rng.random() < 0.25:
+        t = t.shear(*[float(v) for v in rng.uniform(-0.4, 0.4, 6)])
+    t = t.rotate_x(float(rng.uniform(-math.pi, math.pi))).rotate_y(float(rng.uniform(-math.pi, math.pi)))
+    if rng.random() < 0.5:
+        t = t.rotate_z(float(rng.uniform(-math.pi, math.pi)))
+    y = float(rng.uniform(0.2, 2.6)) if lift else float(rng.uniform(-1.0, 1.0))
+    return t.translate(float(rng.uniform(-spread, spread)), y, float(rng.uniform(-2.0, 3.5)))
+
+
+def _pattern(rng, level=0):
+    kind = int(rng.integers(0, 8))
+    t = M.scaling(*[float(v) for v in rng.uniform(0.15, 1.2, 3)]).rotate_y(float(rng.uniform(0, math.pi)))
+    if rng.random() < 0.5:
+        t = t.rotate_z(float(rng.uniform(0, math.pi))).translate(*[float(v) for v in rng.uniform(-1, 1, 3)])
+    sub = (lambda: _pattern(rng, level + 1)) if level < 2 and rng.random() < 0.35 else (lambda: rtc.SolidPattern(_colour(rng)))
+    if kind == 0:
+        return rtc.StripePattern(sub(), sub(), t)
+    if kind == 1:
+        return rtc.CheckerPattern(sub(), sub(), t)
+    if kind == 2:
+        return rtc.BlendedPattern(sub(), sub(), t)
+    if kind == 3:
+        return rtc.GradientPattern(_colour(rng), _colour(rng), t)
+    if kind == 4:
+        return rtc.RingPattern(_colour(rng), _colour(rng), t)
+    if kind == 5:
+        return rtc.RadialGradientPattern(_colour(rng), _colour(rng), t)
+    if kind == 6:
+        return rtc.TestPattern(t)
+    return rtc.SolidPattern(_colour(rng))
+
+
+def _material(rng, glass_ok=True):
+    m = rtc.Material(color=_colour(rng), ambient=float(rng.uniform(0.0, 0.3)), diffuse=float(rng.uniform(0.2, 1.0)),
+                     specular=float(rng.uniform(0.0, 1.0)), shininess=float(rng.uniform(5.0, 300.0)))
+    r = rng.random()
+    if r < 0.25:
+        m.reflectivity = float(rng.uniform(0.1, 1.0))
+    elif r < 0.5 and glass_ok:
+        m.transparency = float(rng.uniform(0.3, 1.0))
+        m.refractive_index = float(rng.uniform(1.0, 2.5))
+        m.reflectivity = float(rng.uniform(0.0, 1.0)) if rng.random() < 0.6 else 0.0
+        m.diffuse = float(rng.uniform(0.05, 0.4))
+    if rng.random() < 0.3:
+        m.pattern = _pattern(rng)
+    if rng.random() < 0.15:
+        m.casts_shadow = False
+    return m
+
+
+def _leaf(rng, spread=3.0, lift=True):
+    kind = int(rng.integers(0, 5))
+    t, m = _transform(rng, spread, lift), _material(rng)
+    if kind == 0:
+        return rtc.Sphere(t, m)
+    if kind == 1:
+        return rtc.Cube(t, m)
+    if kind in (2, 3):
+        ctor = rtc.Cylinder if kind == 2 else rtc.Cone
+        lo = float(rng.uniform(-1.5, 0.2))
+        hi = lo + float(rng.uniform(0.3, 2.0))
+        if rng.random() < 0.12:
+            return ctor(t, m)  # infinite, open
+        return ctor(t, m, lo, hi, bool(rng.random() < 0.6))
+    # a small fan of triangles under a group that decides their material (shape.rs:1520-1532)
+    g = rtc.Group(transformation=t, material=m if rng.random() < 0.7 else rtc.Material())
+    for _ in range(int(rng.integers(1, 5))):
+        p = rng.uniform(-1.0, 1.0, (3, 3))
+        n = rng.uniform(-1.0, 1.0, (3, 3))
+        # glass fans are flat: the interpolated normal of a smooth triangle may point to the other side of its face than
+        # the eye vector says, under_point (intersection.rs:88) then lies on the eye's side, the refracted ray -- which
+        # keeps its bounce budget, world.rs:142 -- meets the same triangle again, and again: the reference overflows its
+        # stack on such a scene (and so does the oracle); this library reports RTC_ERR_OVERFLOW
+        if rng.random() < 0.5 or g.material.transparency > 0.0:
+            g.add_child(rtc.Triangle(tuple(p[0]), tuple(p[1]), tuple(p[2])))
+        else:
+            n /= np.linalg.norm(n, axis=1, keepdims=True)
+            g.add_child(rtc.SmoothTriangle(tuple(p[0]), tuple(p[1]), tuple(p[2]), tuple(n[0]), tuple(n[1]), tuple(n[2])))
+    return g
+
+
+def _csg_operand(rng, level):
+    if level < 2 and rng.random() < 0.3:
+        return _csg(rng, level + 1)
+    kind = int(rng.integers(0, 4))
+    t = M.scaling(*[float(v) for v in rng.uniform(0.5, 1.1, 3)]).rotate_y(float(rng.uniform(0, math.pi)))
+    t = t.translate(*[float(v) for v in rng.uniform(-0.6, 0.6, 3)])
+    m = _material(rng)
+    if kind == 0:
+        return rtc.Sphere(t, m)
+    if kind == 1:
+        return rtc.Cube(t, m)
+    if kind == 2:
+        return rtc.Cylinder(t, m, -1.0, 1.0, True)
+    return rtc.Group(transformation=t, children=[rtc.Sphere(M.translation(-0.4, 0, 0), m), rtc.Cube(M.scaling(0.5, 0.5, 0.5).translate(0.5, 0, 0), m)])
+
+
+def _csg(rng, level=0):
+    op = [rtc.CsgUnion, rtc.CsgIntersection, rtc.CsgDifference][int(rng.integers(0, 3))]
+    return op(_csg_operand(rng, level), _csg_operand(rng, level))
+
+
+def _group(rng, level=0):
+    g = rtc.Group(transformation=_transform(rng, 2.0 if level == 0 else 1.0, lift=(level == 0)))
+    for _ in range(int(rng.integers(2, 6))):
+        if level < 2 and rng.random() < 0.3:
+            g.add_child(_group(rng, level + 1))
+        else:
+            g.add_child(_leaf(rng, 1.2, lift=False))
+    return g
+
+
+def random_scene(seed, w=120, h=80):
+    """(world, camera, depth) of seed"""
+    rng = np.random.default_rng(seed)
+    objs = []
+    if rng.random() < 0.8:
+        objs.append(rtc.Plane(material=_material(rng, glass_ok=False)))
+    if rng.random() < 0.4:
+        objs.append(rtc.Plane(M.rotation_x(math.pi / 2).translate(0, 0, float(rng.uniform(4, 8))), _material(rng, glass_ok=False)))
+    for _ in range(int(rng.integers(3, 14))):
+        r = rng.random()
+        if r < 0.6:
+            objs.append(_leaf(rng))
+        elif r < 0.85:
+            objs.append(_group(rng))
+        else:
+            # the Csg node has no transformation of its own: wrap it in a group to place it
+            objs.append(rtc.Group(transformation=_transform(rng, 2.5), children=[_csg(rng)]))
+    n_lights = int(rng.integers(1, 4))
+    lights = []
+    for k in range(n_lights):
+        pos = (float(rng.uniform(-8, 8)), float(rng.uniform(4, 10)), float(rng.uniform(-9, -2)))
+        if rng.random() < 0.2:
+            lights.append(rtc.AreaLight(pos, (float(rng.uniform(0.5, 2)), 0, 0), int(rng.integers(1, 4)),
+                                        (0, float(rng.uniform(0.5, 2)), 0), int(rng.integers(1, 4)), _colour(rng, 0.2, 0.9)))
+        else:
+            lights.append(rtc.PointLight(pos, _colour(rng, 0.2, 0.9)))
+    # the reference re-traces the secondary rays once per light (world.rs:45-68): keep the oracle's tree in bounds
+    depth = int(rng.integers(0, 6)) if n_lights == 1 else int(rng.integers(0, 4))
+    if rng.random() < 0.25:
+        w, h = h, w  # portrait
+    frm = (float(rng.uniform(-4, 4)), float(rng.uniform(0.5, 5)), float(rng.uniform(-9, -5)))
+    to = (float(rng.uniform(-1, 1)), float(rng.uniform(0.3, 1.8)), float(rng.uniform(-0.5, 1.0)))
+    cam = rtc.Camera(w, h, float(rng.uniform(0.6, 1.5)), rtc.compute_view_transformation(frm, to, (0, 1, 0)))
+    return rtc.World(objs, lights), cam, depth

@@ -43,6 +43,7 @@ class Stats(C.Structure):
         ("shadow_rays", C.c_uint64),
         ("secondary_rays", C.c_uint64),
         ("seconds", C.c_double),
+        ("diverged_pixels", C.c_uint64),
     ]
 
 
@@ -337,7 +338,7 @@ class World:
             raise ValueError("NonInvertibleMatrix")
         assert rc == OK, rc
         self.last_stats = dict(primary=st.primary_rays, shadow=st.shadow_rays, secondary=st.secondary_rays,
-                               seconds=st.seconds)
+                               seconds=st.seconds, diverged=st.diverged_pixels)
         return out
 
     def render_pixels(self, xy, threads=None, depth=None):
@@ -355,7 +356,7 @@ class World:
             raise ValueError("NonInvertibleMatrix")
         assert rc == OK, rc
         self.last_stats = dict(primary=st.primary_rays, shadow=st.shadow_rays, secondary=st.secondary_rays,
-                               seconds=st.seconds)
+                               seconds=st.seconds, diverged=st.diverged_pixels)
         return out
 
     # unit-level
