@@ -162,3 +162,78 @@ def random_scene(seed, w=120, h=80):
     to = (float(rng.uniform(-1, 1)), float(rng.uniform(0.3, 1.8)), float(rng.uniform(-0.5, 1.0)))
     cam = rtc.Camera(w, h, float(rng.uniform(0.6, 1.5)), rtc.compute_view_transformation(frm, to, (0, 1, 0)))
     return rtc.World(objs, lights), cam, depth
+
+
+def crowd_scene(seed, n=36_000, w=480, h=270):
+    """(world, camera): `n` small shapes of every kind in a slab in front of the camera -- enough for the hierarchy to
+    be stored quantised (more than 1 MB of f32 nodes, rtc_scene.cpp build_bvh) with leaves that are NOT all compact
+    spheres: rotated and sheared spheres, cubes, capped cylinders and cones, triangles in groups, nested groups; one in
+    five glass or mirror (spheres and cubes only: closed convex shapes let every refracted ray out again)"""
+    rng = np.random.default_rng(seed)
+    objs = [rtc.Plane(material=rtc.Material(color=(0.8, 0.8, 0.75), reflectivity=0.2, specular=0.1,
+                                            pattern=rtc.CheckerPattern(rtc.SolidPattern((0.9, 0.9, 0.9)), rtc.SolidPattern((0.3, 0.3, 0.35)))))]
+    mats = []
+    for _ in range(64):
+        m = rtc.Material(color=_colour(rng), ambient=float(rng.uniform(0.05, 0.2)), diffuse=float(rng.uniform(0.4, 0.9)),
+                         specular=float(rng.uniform(0.0, 0.9)), shininess=float(rng.uniform(10.0, 250.0)))
+        if rng.random() < 0.2:
+            m.pattern = _pattern(rng, level=2)
+        mats.append(m)
+    glass = [rtc.Material(color=_colour(rng), diffuse=0.1, ambient=0.05, transparency=float(rng.uniform(0.6, 1.0)),
+                          refractive_index=float(rng.uniform(1.1, 2.0)), reflectivity=float(rng.uniform(0.0, 0.9)))
+             for _ in range(8)]
+    mirror = [rtc.Material(color=_colour(rng), diffuse=0.4, reflectivity=float(rng.uniform(0.3, 1.0))) for _ in range(8)]
+
+    def place(scale_lo=0.04, scale_hi=0.16, axis_aligned=False):
+        t = M.scaling(*[float(v) for v in rng.uniform(scale_lo, scale_hi, 3)])
+        if not axis_aligned:
+            if rng.random() < 0.15:
+                t = t.shear(*[float(v) for v in rng.uniform(-0.3, 0.3, 6)])
+            t = t.rotate_x(float(rng.uniform(-math.pi, math.pi))).rotate_z(float(rng.uniform(-math.pi, math.pi)))
+        return t.translate(float(rng.uniform(-9, 9)), float(rng.uniform(0.1, 5.0)), float(rng.uniform(-3, 14)))
+
+    def leaf():
+        r = rng.random()
+        kind = int(rng.integers(0, 6))
+        if r < 0.1 and kind < 2:
+            m = glass[int(rng.integers(0, 8))]
+        elif r < 0.2:
+            m = mirror[int(rng.integers(0, 8))]
+        else:
+            m = mats[int(rng.integers(0, 64))]
+        if kind == 0:
+            # half of the spheres keep a diagonal inverse: candidates for the compact 64-byte leaf records
+            return rtc.Sphere(place(axis_aligned=bool(rng.random() < 0.5)), m)
+        if kind == 1:
+            return rtc.Cube(place(), m)
+        if kind == 2:
+            return rtc.Cylinder(place(), m, float(rng.uniform(-1.0, 0.0)), float(rng.uniform(0.2, 1.0)), bool(rng.random() < 0.7))
+        if kind == 3:
+            lo = float(rng.uniform(-1.0, 0.3))
+            # open cones cannot be bounded (an unclipped hit anywhere along the double cone when |a| < EPSILON,
+            # shape.rs:1219-1225): a few of them only, they go to the list every ray tests in full
+            return rtc.Cone(place(), m, lo, lo + float(rng.uniform(0.3, 1.0)), bool(rng.random() < 0.995))
+        pts = rng.uniform(-1.0, 1.0, (int(rng.integers(1, 4)), 9))
+        if kind == 4:
+            return rtc.Group(transformation=place(0.08, 0.3), children=[rtc.TriangleMesh(pts)], material=m)
+        nrm = rng.uniform(-1.0, 1.0, pts.shape).reshape(-1, 3, 3)
+        nrm /= np.linalg.norm(nrm, axis=2, keepdims=True)
+        return rtc.Group(transformation=place(0.08, 0.3), children=[rtc.TriangleMesh(pts, nrm.reshape(-1, 9))], material=m)
+
+    count = 0
+    while count < n:
+        if rng.random() < 0.02:
+            # a cluster: a group (sometimes nested) with a transformation of its own
+            g = rtc.Group(transformation=M.rotation_y(float(rng.uniform(0, math.pi))).scale(*[float(v) for v in rng.uniform(0.6, 1.4, 3)]))
+            inner = rtc.Group(transformation=M.translation(float(rng.uniform(-1, 1)), 0.0, float(rng.uniform(-1, 1))))
+            for _ in range(int(rng.integers(4, 12))):
+                (inner if rng.random() < 0.4 else g).add_child(leaf())
+                count += 1
+            g.add_child(inner)
+            objs.append(g)
+        else:
+            objs.append(leaf())
+            count += 1
+    lights = [rtc.PointLight((-12, 14, -10), (0.9, 0.9, 0.9))]
+    cam = rtc.Camera(w, h, 1.0, rtc.compute_view_transformation((0.5, 3.2, -9), (0, 1.8, 3), (0, 1, 0)))
+    return rtc.World(objs, lights), cam

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import scene_feed as sf
-from fuzz_scenes import random_scene
+from fuzz_scenes import crowd_scene, random_scene
 from scene_feed import rtc
 
 pytestmark = pytest.mark.gpu
@@ -66,3 +66,38 @@ def test_random_scene_matches_oracle(seed):
     assert float(np.max(np.abs(default[good] - static[good]))) < 1e-12
     assert float(np.max(np.abs(persistent[good] - static[good]))) < 1e-12
     assert np.all(static[-1] == 0.0) and np.all(static[:, -1] == 0.0)
+
+
+@pytest.mark.parametrize("seed", [7, 8])
+def test_crowd_of_mixed_shapes_in_a_quantised_hierarchy(seed):
+    # 36 000 small shapes of every kind: the hierarchy is stored quantised (more than 16 384 inner nodes), its leaves
+    # mix compact sphere records with full records of cubes, cylinders, cones and triangles under groups -- the stress
+    # scene of the bench has spheres and one mesh only.  Auto schedule = persistent (more than 64 transparent shapes).
+    world, cam = crowd_scene(seed)
+    scene = cam.compile(world, device=0)
+    try:
+        info = scene.info()
+        assert info["n_bvh_nodes"] > 16384 and info["n_unbounded"] > 1
+        default = scene.render()
+        ms = scene.last_stats["kernel_ms"]
+        static = scene.render(schedule=1, exchange=1)
+        persistent_whole = scene.render(schedule=2, exchange=1)
+        ntiles = (cam.vsize + 7) // 8
+        kw = dict(tile_rows=8, tile_index=ntiles // 2, tile_count=ntiles, depth=2, schedule=1, exchange=1)
+        bvh = scene.render(use_bvh=1, **kw)
+        brute = scene.render(use_bvh=2, **kw)
+    finally:
+        scene.close()
+    rng = np.random.default_rng(seed)
+    xy = np.stack([rng.integers(0, cam.hsize - 1, 2000), rng.integers(0, cam.vsize - 1, 2000)], axis=1)
+    ow = sf.to_oracle(world, cam)
+    ref = ow.render_pixels(xy)
+    assert ow.last_stats["diverged"] == 0
+    rep = sf.compare(static[xy[:, 1], xy[:, 0]], ref)
+    print(f"[fuzz] crowd seed {seed}: {info['n_prims']} primitives, {info['n_bvh_nodes']} nodes, {info['n_unbounded']} "
+          f"unbounded, kernel {ms:.2f} ms, oracle {ow.last_stats['seconds']:.1f} s for {len(xy)} pixels: {rep}")
+    assert rep["nan"] == 0 and rep["max_8bit"] <= 1 and rep["pixels_over_1"] == 0 and rep["max_abs"] < F64_TOL, rep
+    assert float(np.abs(ref).sum()) > 0 and float(np.abs(bvh).sum()) > 0
+    assert np.array_equal(bvh, brute)
+    assert np.array_equal(static, persistent_whole)  # one lane per pixel from start to end: bit-equal schedules
+    assert float(np.max(np.abs(default - static))) < 1e-12
