@@ -217,7 +217,12 @@ int rtc_render(rtc_scene *scene, const rtc_render_opts *opts, double *rgb_out, r
  * reports it itself; after the asynchronous rtc_render_device ask rtc_scene_check().  The canvas is still written,
  * but the pixels concerned are UNDEFINED: NaN where max_rays_per_pixel was exceeded, otherwise a finite colour that
  * lacks the contributions that were dropped -- discard the frame.  The calls leave the caller's current HIP device as
- * they found it. */
+ * they found it.
+ * Scenes the reference does not finish: refraction keeps the bounce budget (world.rs:142), so a ray caught between
+ * refracting surfaces (the apex of a transparent double cone, a transparent smooth triangle whose normals disagree with
+ * its face) recurses until the reference overflows its stack.  Here such a ray ends at max_rays_per_pixel
+ * (RTC_ERR_OVERFLOW, NaN in that pixel) or, earlier, where its weight -- the product of the transparencies on its way --
+ * has underflowed to exactly 0.0; all other pixels of the frame are the reference's. */
 
 /* Synchronises the scene's device and reports the state of the most recent launch on this scene: RTC_OK,
  * RTC_ERR_OVERFLOW (see above) or RTC_ERR_HIP (the kernel faulted). */
