@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--schedule", type=int, default=0, help="0 auto, 1 workgroup per tile, 2 persistent (A/B only)")
     ap.add_argument("--extra-stress", action="store_true", help="include the (slow) stress scene in --extra")
     ap.add_argument("--extra", action="store_true", help="(default at N=1) also time the reference sample scenes")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the frames-in-flight measurement")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-flavours", action="store_true", help="(accepted and ignored: the contracted flavour is gone)")
     ap.add_argument("--parity-pixels", type=int, default=0,
@@ -368,6 +369,39 @@ def main():
                                    "within_tolerance": bool(rep["pixels_over_1"] == 0 and rep["nan"] == 0)}
             s2.close()
         out["extra_workloads"] = extra
+
+    if not args.no_pipelined and not distributed and WORKLOADS[args.workload][0] == "stress" and not args.schedule:
+        # Frames in flight (reported BESIDE the headline, never as `value`): the same frame launched alternately through
+        # two scene handles (each its own work buffer) on two streams with rtc_render_opts.tail_waves = 64 -- at the end
+        # of a frame all but 64 waves of the persistent grid leave, the next frame's grid moves in while the last ray
+        # trees finish, so the end of a frame (a chain of dependent rays, ~43 ms whatever the pixel count) no longer
+        # costs throughput.  `value` above stays one frame at a time: that is what `roofline` and profiles/ describe.
+        scene_b = cam.compile(world, device=local_rank)
+        pbufs = [torch.zeros((vsize, hsize, 3), dtype=torch.float64, device=dev) for _ in range(2)]
+        pstreams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        pk = dict(ropts, tail_waves=64)
+        handles = [scene, scene_b]
+        frames = 2 * max(2, min(args.steps, 8) // 2)
+
+        def in_flight(n):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for k in range(n):
+                handles[k % 2].render_device(pbufs[k % 2].data_ptr(), pstreams[k % 2].cuda_stream, **pk)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t1) * 1e3 / n
+
+        in_flight(2)
+        pms = in_flight(frames)
+        scene.check()
+        scene_b.check()
+        out["frames_in_flight"] = {
+            "frames_in_flight": 2, "tail_waves": 64, "frames": frames, "ms_per_frame": pms,
+            "Mrays_per_s": rays_per_frame / pms / 1e3,
+            "max_abs_vs_timed_frame": max(float((pb - buf).abs().max()) for pb in pbufs),
+            "what": "throughput of a stream of frames, two in flight on two HIP streams (two scene handles); not the "
+                    "headline: `value`, `ms_per_step` and `roofline` are one frame at a time"}
+        scene_b.close()
 
     if not args.no_cpu_baseline and not distributed:
         # The reference is Rust and can not be built here (no toolchain): the baseline is the C oracle (brute force,

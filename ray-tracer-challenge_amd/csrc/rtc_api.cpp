@@ -351,6 +351,12 @@ static int resolve_params(Scene &s, const rtc_render_opts *opts_in, DRenderParam
     // auto: deep ray trees come from transparent surfaces (refraction keeps the bounce budget, world.rs:142)
     p.persistent = (o.schedule == 2) ? 1u : (o.schedule == 1) ? 0u : (s.n_transparent_prims > 64 ? 1u : 0u);
     p.share = (o.exchange == 1) ? 0u : 1u;
+    // (share = 1 + N: at most N waves stay at the end of a frame to take over rays of others, rtc_render_opts.tail_waves)
+    if (p.share && o.tail_waves) p.share = 1u + std::min<uint32_t>(o.tail_waves, 0x7ffffffeu);
+    {
+        const char *e = getenv("RTC_TAIL_WAVES");  // (A/B)
+        if (p.share && e && atoi(e) > 0) p.share = 1u + (unsigned)atoi(e);
+    }
     p.max_rays = o.max_rays_per_pixel;
     p.tiles_x = (s.hsize + 7u) / 8u;
     p.tiles_y = (p.local_rows + 7u) / 8u;

@@ -1557,14 +1557,19 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                 if (lane == 0) {
                     unsigned *my_state = work + RTC_WORK_STATES + blockIdx.x;
                     atomicSub(work + RTC_WORK_BUSY, 1u);
+                    // frames in flight (prm.share = 1 + cap): once `cap` waves wait for rays of others, further waves
+                    // leave instead -- their slots go to the next frame's grid, which is already queued on another stream
+                    const bool leave = prm.share > 1u && wb_load(work + RTC_WORK_HUNGRY) >= prm.share - 1u;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (!leave) {
                     wb_store(my_state, RTC_MB_HUNGRY);
                     atomicAdd(work + RTC_WORK_HUNGRY, 1u);
                     const unsigned slot = atomicAdd(work + RTC_WORK_HINT_TAIL, 1u);
                     wb_store(work + RTC_WORK_HINTS + (slot & 255u), blockIdx.x);
+                    }
                     // waits for rays, or for every wave to have run out of its own (bounded: a donor between its
                     // claim and RTC_MB_FULL runs straight-line code; the cap only guards against the unforeseen)
-                    for (unsigned spin = 0;; spin++) {
+                    for (unsigned spin = 0; !leave; spin++) {
                         const unsigned stt = wb_load(my_state);
                         if (stt == RTC_MB_FULL) {
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -2003,7 +2008,8 @@ static void launch_variant(const DScene &scene, DRenderParams &params, double *d
             params.refuse_oversize = 2u;  // reported by launch_render; nothing is launched
             return;
         }
-        params.share = (params.share != 0u && share_env != 0 && waves <= RTC_MAX_WAVES) ? 1u : 0u;
+        // (share = 1 + cap: at most `cap` waves wait for rays of others at the end of the frame, the rest leave)
+        params.share = (params.share != 0u && share_env != 0 && waves <= RTC_MAX_WAVES) ? params.share : 0u;
         params.n_waves = waves;
         static const unsigned stay_env = getenv("RTC_STAY_MIN") ? (unsigned)atoi(getenv("RTC_STAY_MIN")) : 0u;
         params.stay_min = stay_env ? stay_env : RTC_STAY_MIN;

@@ -288,6 +288,35 @@ def test_alternating_shares_on_a_side_stream_keep_their_own_tile_order():
         scene.close()
 
 
+def test_frames_in_flight_on_two_streams_with_tail_waves():
+    # rtc_render_opts.tail_waves: at the end of a frame of the persistent schedule only N waves stay to take over rays of
+    # others, the rest leave -- so that the next frame's grid (another scene handle = another work buffer, another stream)
+    # moves in while the last ray trees finish.  Six frames alternate between two handles and two streams without a
+    # synchronisation; every canvas must be the frame itself (the parts of split pixels are added in another order).
+    import torch
+    world, cam = rtc.stress_scene.build(20_000, 960, 540, with_teapot=False)
+    a, b = cam.compile(world, device=0), cam.compile(world, device=0)
+    try:
+        want = a.render(schedule=2, exchange=1)
+        lone = a.render(schedule=2, tail_waves=8)  # a frame alone: slower, same pixels
+        assert float(np.max(np.abs(lone - want))) < 1e-12
+        streams = [torch.cuda.Stream(device="cuda:0") for _ in range(2)]
+        bufs = [torch.full((cam.vsize, cam.hsize, 3), float("nan"), dtype=torch.float64, device="cuda:0") for _ in range(6)]
+        torch.cuda.synchronize()
+        for i, buf in enumerate(bufs):
+            (a, b)[i % 2].render_device(buf.data_ptr(), streams[i % 2].cuda_stream, schedule=2, tail_waves=8)
+        torch.cuda.synchronize()
+        a.check()
+        b.check()
+        for i, buf in enumerate(bufs):
+            got = buf.cpu().numpy()
+            assert not np.isnan(got).any(), i
+            assert float(np.max(np.abs(got - want))) < 1e-12, i
+    finally:
+        a.close()
+        b.close()
+
+
 def test_two_real_gpus_equal_one():
     import torch
     if torch.cuda.device_count() < 2:

@@ -1,0 +1,42 @@
+"""Frames in flight: K frames of the stress scene launched back to back on ONE stream against the same K frames
+alternating between TWO scenes / streams / canvases, with RTC_TAIL_WAVES (waves that may wait for rays of others at the
+end of a frame; the rest leave and free their slots for the next frame's grid).
+Usage: tools/pipeline_probe.py [w h frames] [tile_count]"""
+import importlib, os, sys, time
+import torch
+sys.path.insert(0, '.')
+rtc = importlib.import_module("ray-tracer-challenge_amd")
+w, h, K = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3840, 2160, 6)
+tc = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+world, cam = rtc.stress_scene.build(100000, w, h)
+dev = torch.device("cuda:0")
+scenes = [cam.compile(world, device=0) for _ in range(2)]
+kw = dict(tile_rows=8, tile_index=0, tile_count=tc) if tc > 1 else {}
+rows = scenes[0].local_rows(**kw) if tc > 1 else h
+bufs = [torch.zeros((rows, w, 3), dtype=torch.float64, device=dev) for _ in range(2)]
+streams = [torch.cuda.Stream(dev) for _ in range(2)]
+
+
+def run(n_streams, frames):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(frames):
+        j = k % n_streams
+        scenes[j].render_device(bufs[j].data_ptr(), streams[j].cuda_stream, **kw)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / frames
+
+
+for cap in ("0", "4096", "1024", "256", "64", "16"):
+    os.environ["RTC_TAIL_WAVES"] = cap
+    run(1, 1)
+    one = run(1, K)
+    two = run(2, K)
+    ref = bufs[0].clone()
+    os.environ["RTC_TAIL_WAVES"] = "0"
+    run(1, 1)
+    d = float((bufs[0] - ref).abs().max())
+    for s in scenes:
+        s.check()
+    print("share %d/%d cap %5s: one stream %.1f ms/frame, two streams %.1f ms/frame  (max |delta| vs uncapped frame %.1e)"
+          % (1, tc, cap, one, two, d), flush=True)

@@ -5,7 +5,7 @@ CNT=$1; LIB=${2:-}; shift 2 || shift $#
 OUT=gpurun_out/pmc1_$$
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-timeout -s KILL 150 rocprofv3 --pmc $CNT -d $OUT -o pmc -- python3 bench.py --no-cpu-baseline --no-extra --no-flavours --steps 2 --warmup 1 "$@" > $OUT/log.txt 2>&1 || { echo "pass failed"; tail -3 $OUT/log.txt; }
+timeout -s KILL 150 rocprofv3 --pmc $CNT -d $OUT -o pmc -- python3 bench.py --no-cpu-baseline --no-pipelined --no-extra --no-flavours --steps 2 --warmup 1 "$@" > $OUT/log.txt 2>&1 || { echo "pass failed"; tail -3 $OUT/log.txt; }
 python3 - "$OUT" <<'PY'
 import sqlite3, glob, sys
 for d in sorted(glob.glob(sys.argv[1] + "/**/*.db", recursive=True)):

@@ -5,7 +5,7 @@ TAG=$1; LIB=${2:-}; shift 2 || shift $#
 OUT=gpurun_out/pmcq_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --no-cpu-baseline --no-extra --no-flavours --steps 2 --warmup 1 $*"
+BENCH="python3 bench.py --no-cpu-baseline --no-pipelined --no-extra --no-flavours --steps 2 --warmup 1 $*"
 timeout -k 10 120 $BENCH > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -3 $OUT/bench.err; exit 1; }
 python3 tools/summarize_bench.py $OUT/bench.json
 python3 - $OUT/bench.json <<'PY'

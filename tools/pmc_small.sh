@@ -8,7 +8,7 @@ for lib in "" "$@"; do
   if [ -n "$lib" ]; then export RTC_AMD_LIB=$PWD/$lib; else unset RTC_AMD_LIB; fi
   name=$(basename "${lib:-in-tree}" .so)
   for wl in $WLS; do
-    BENCH="python3 bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 3 --workload $wl"
+    BENCH="python3 bench.py --no-cpu-baseline --no-pipelined --no-extra --steps 20 --warmup 3 --workload $wl"
     timeout -k 10 120 $BENCH > $OUT/$name.$wl.json 2> $OUT/$name.$wl.err || { echo "$name $wl bench failed"; tail -3 $OUT/$name.$wl.err; exit 1; }
     timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/$name.$wl.pmc -o pmc -- $BENCH > $OUT/$name.$wl.log 2>&1 || echo "$name $wl pmc pass failed"
     python3 - $OUT/$name.$wl.json $OUT/$name.$wl.pmc "$name" $wl <<'PY'

@@ -1,7 +1,7 @@
 #!/bin/bash
 # FETCH_SIZE / WRITE_SIZE of the headline frame for the in-tree library and every library given.  Usage: tools/pmc_traffic.sh [lib.so ...]
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --no-cpu-baseline --no-extra --steps 2 --warmup 1"
+BENCH="python3 bench.py --no-cpu-baseline --no-pipelined --no-extra --steps 2 --warmup 1"
 for lib in "" "$@"; do
   if [ -n "$lib" ]; then export RTC_AMD_LIB=$PWD/$lib; else unset RTC_AMD_LIB; fi
   name=$(basename "${lib:-in-tree}" .so)

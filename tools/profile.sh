@@ -6,7 +6,7 @@ TAG=${1:-r1}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --no-cpu-baseline --no-extra --no-flavours $*"
+BENCH="python3 bench.py --no-cpu-baseline --no-pipelined --no-extra --no-flavours $*"
 echo "== kernel trace + stats" | tee $OUT/log.txt
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH >> $OUT/log.txt 2>&1 || exit 1
 for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
