@@ -372,14 +372,14 @@ def main():
 
     if not args.no_pipelined and not distributed and WORKLOADS[args.workload][0] == "stress" and not args.schedule:
         # Frames in flight (reported BESIDE the headline, never as `value`): the same frame launched alternately through
-        # two scene handles (each its own work buffer) on two streams with rtc_render_opts.tail_waves = 64 -- at the end
-        # of a frame all but 64 waves of the persistent grid leave, the next frame's grid moves in while the last ray
-        # trees finish, so the end of a frame (a chain of dependent rays, ~43 ms whatever the pixel count) no longer
+        # two scene handles (each its own work buffer) on two streams with rtc_render_opts.tail_polls = 32 -- at the end
+        # of a frame a wave without work looks 32 times for rays of others and leaves, the next frame's grid moves in
+        # while the last ray trees finish, so the end of a frame (a chain of dependent rays, ~43 ms whatever the pixel count) no longer
         # costs throughput.  `value` above stays one frame at a time: that is what `roofline` and profiles/ describe.
         scene_b = cam.compile(world, device=local_rank)
         pbufs = [torch.zeros((vsize, hsize, 3), dtype=torch.float64, device=dev) for _ in range(2)]
         pstreams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-        pk = dict(ropts, tail_waves=64)
+        pk = dict(ropts, tail_polls=32)
         handles = [scene, scene_b]
         frames = 2 * max(2, min(args.steps, 8) // 2)
 
@@ -396,7 +396,7 @@ def main():
         scene.check()
         scene_b.check()
         out["frames_in_flight"] = {
-            "frames_in_flight": 2, "tail_waves": 64, "frames": frames, "ms_per_frame": pms,
+            "frames_in_flight": 2, "tail_polls": 32, "frames": frames, "ms_per_frame": pms,
             "Mrays_per_s": rays_per_frame / pms / 1e3,
             "max_abs_vs_timed_frame": max(float((pb - buf).abs().max()) for pb in pbufs),
             "what": "throughput of a stream of frames, two in flight on two HIP streams (two scene handles); not the "

@@ -100,16 +100,15 @@ typedef struct rtc_render_opts {
                             grazes an edge landed on its other side and glass / mirrors carried that on, up to 95/255 in
                             single pixels; it did not meet the parity bar and was removed.  Any other value is refused
                             with RTC_ERR_INVALID.) */
-    uint32_t tail_waves; /* persistent schedule with the exchange on.  0 = every wave of the grid that has run out of work
-                            stays resident until the frame ends and takes over waiting rays of others: the shortest time
-                            for ONE frame.  N > 0 = at most N waves stay for that, the others leave and free their slots:
-                            for callers that keep two or more frames in flight on different streams (rtc_render_device
-                            with one scene handle -- its own work buffer -- and one stream per frame in flight): the
-                            grid of the next frame moves in while this frame's last ray trees finish, so the end of a
-                            frame -- a chain of dependent rays that does not shrink with the pixel count -- costs
-                            throughput no longer (stress 4K 975 -> 951 ms per frame, one eighth of the frame 190 -> 145 ms
-                            with N = 64; a frame alone gets slower with N > 0).  Same pixels as with 0 (to the order of
-                            the additions of split pixels) */
+    uint32_t tail_polls; /* persistent schedule with the exchange on.  0 = a wave of the grid that has run out of work stays
+                            resident until the frame ends and takes over waiting rays of others: the shortest time for ONE
+                            frame.  N > 0 = such a wave looks N times (every ~5 us) for rays of others and then leaves,
+                            freeing its slot: for callers that keep two or more frames in flight on different streams
+                            (rtc_render_device with one scene handle -- its own work buffer -- and one stream per frame
+                            in flight): the grid of the next frame moves in while this frame's last ray trees finish, so
+                            the end of a frame -- a chain of dependent rays that does not shrink with the pixel count --
+                            costs throughput no longer (a frame alone gets slower with N > 0).
+                            Same pixels as with 0 (to the order of the additions of split pixels) */
     uint32_t reserved[5];
 } rtc_render_opts;
 

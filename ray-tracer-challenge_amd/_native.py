@@ -56,7 +56,7 @@ class RenderOpts(C.Structure):
         ("exchange", C.c_uint32),
         ("max_rays_per_pixel", C.c_uint32),
         ("fp_mode", C.c_uint32),
-        ("tail_waves", C.c_uint32),
+        ("tail_polls", C.c_uint32),
         ("reserved", C.c_uint32 * 5),
     ]
 

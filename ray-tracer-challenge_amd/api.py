@@ -420,13 +420,13 @@ class CompiledScene:
 
     # ---- rendering ----
     def _opts(self, depth=5, tile_rows=0, tile_index=0, tile_count=1, use_bvh=0, collect_stats=False, schedule=0,
-              exchange=0, max_rays_per_pixel=0, fp_mode=0, tail_waves=0):
+              exchange=0, max_rays_per_pixel=0, fp_mode=0, tail_polls=0):
         o = N.RenderOpts()
         self.L.rtc_render_opts_default(C.byref(o))
         o.depth, o.tile_rows, o.tile_index, o.tile_count = depth, tile_rows, tile_index, tile_count
         o.use_bvh, o.collect_stats = use_bvh, 1 if collect_stats else 0
         o.schedule, o.exchange, o.max_rays_per_pixel, o.fp_mode = schedule, exchange, max_rays_per_pixel, fp_mode
-        o.tail_waves = tail_waves
+        o.tail_polls = tail_polls
         return o
 
     def render(self, out=None, **kw):

@@ -351,10 +351,11 @@ static int resolve_params(Scene &s, const rtc_render_opts *opts_in, DRenderParam
     // auto: deep ray trees come from transparent surfaces (refraction keeps the bounce budget, world.rs:142)
     p.persistent = (o.schedule == 2) ? 1u : (o.schedule == 1) ? 0u : (s.n_transparent_prims > 64 ? 1u : 0u);
     p.share = (o.exchange == 1) ? 0u : 1u;
-    // (share = 1 + N: at most N waves stay at the end of a frame to take over rays of others, rtc_render_opts.tail_waves)
-    if (p.share && o.tail_waves) p.share = 1u + std::min<uint32_t>(o.tail_waves, 0x7ffffffeu);
+    // (share = 1 + N: a wave without work waits N polls for rays of others before it leaves, rtc_render_opts.tail_polls;
+    // share = 1: until the frame ends)
+    if (p.share && o.tail_polls) p.share = 1u + std::min<uint32_t>(o.tail_polls, 1u << 20);
     {
-        const char *e = getenv("RTC_TAIL_WAVES");  // (A/B)
+        const char *e = getenv("RTC_TAIL_POLLS");  // (A/B)
         if (p.share && e && atoi(e) > 0) p.share = 1u + (unsigned)atoi(e);
     }
     p.max_rays = o.max_rays_per_pixel;

@@ -1558,30 +1558,27 @@ __global__ __launch_bounds__(RTC_WAVE, PERSISTENT ? RTC_MIN_WAVES_PERSISTENT : R
                     unsigned *my_state = work + RTC_WORK_STATES + blockIdx.x;
                     atomicSub(work + RTC_WORK_BUSY, 1u);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    // frames in flight (rtc_render_opts.tail_waves; prm.share = 1 + cap, 2^32 - 1 without one): once `cap`
-                    // waves wait for rays of others, further waves leave instead -- their slots go to the next frame's
-                    // grid, which is already queued on another stream
-                    if (wb_load(work + RTC_WORK_HUNGRY) < prm.share - 1u) {
-                        wb_store(my_state, RTC_MB_HUNGRY);
-                        atomicAdd(work + RTC_WORK_HUNGRY, 1u);
-                        const unsigned slot = atomicAdd(work + RTC_WORK_HINT_TAIL, 1u);
-                        wb_store(work + RTC_WORK_HINTS + (slot & 255u), blockIdx.x);
-                        // waits for rays, or for every wave to have run out of its own (bounded: a donor between its
-                        // claim and RTC_MB_FULL runs straight-line code; the cap only guards against the unforeseen)
-                        for (unsigned spin = 0;; spin++) {
-                            const unsigned stt = wb_load(my_state);
-                            if (stt == RTC_MB_FULL) {
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                                got = (int)wb_load(work + RTC_WORK_COUNTS + blockIdx.x);
-                                break;
-                            }
-                            if (stt == RTC_MB_HUNGRY && (wb_load(work + RTC_WORK_BUSY) == 0u || spin > (1u << 20)) &&
-                                wb_cas(my_state, RTC_MB_HUNGRY, RTC_MB_CLOSED)) {
-                                atomicSub(work + RTC_WORK_HUNGRY, 1u);
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(127);
+                    wb_store(my_state, RTC_MB_HUNGRY);
+                    atomicAdd(work + RTC_WORK_HUNGRY, 1u);
+                    const unsigned slot = atomicAdd(work + RTC_WORK_HINT_TAIL, 1u);
+                    wb_store(work + RTC_WORK_HINTS + (slot & 255u), blockIdx.x);
+                    // waits for rays, or for every wave to have run out of its own -- or, with frames in flight
+                    // (rtc_render_opts.tail_polls), until its patience ends: prm.share is the number of polls (2^20 when
+                    // the wave is to stay until the frame ends: bounded anyway -- a donor between its claim and
+                    // RTC_MB_FULL runs straight-line code; the cap only guards against the unforeseen)
+                    for (unsigned spin = 0;; spin++) {
+                        const unsigned stt = wb_load(my_state);
+                        if (stt == RTC_MB_FULL) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                            got = (int)wb_load(work + RTC_WORK_COUNTS + blockIdx.x);
+                            break;
                         }
+                        if (stt == RTC_MB_HUNGRY && (wb_load(work + RTC_WORK_BUSY) == 0u || spin > prm.share) &&
+                            wb_cas(my_state, RTC_MB_HUNGRY, RTC_MB_CLOSED)) {
+                            atomicSub(work + RTC_WORK_HUNGRY, 1u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(127);
                     }
                     if (got > 0) atomicAdd(work + RTC_WORK_BUSY, 1u);
                 }
@@ -2008,9 +2005,9 @@ static void launch_variant(const DScene &scene, DRenderParams &params, double *d
             params.refuse_oversize = 2u;  // reported by launch_render; nothing is launched
             return;
         }
-        // (share = 1 + cap: at most `cap` waves wait for rays of others at the end of the frame, the rest leave;
-        // without a cap 2^32 - 1)
-        params.share = (params.share != 0u && share_env != 0 && waves <= RTC_MAX_WAVES) ? (params.share > 1u ? params.share : 0xffffffffu) : 0u;
+        // (share > 1: the polls a wave without work waits for rays of others before it leaves, rtc_render_opts.tail_polls;
+        // 1 = until the frame ends, i.e. the guard value 2^20)
+        params.share = (params.share != 0u && share_env != 0 && waves <= RTC_MAX_WAVES) ? (params.share > 1u ? params.share : (1u << 20)) : 0u;
         params.n_waves = waves;
         static const unsigned stay_env = getenv("RTC_STAY_MIN") ? (unsigned)atoi(getenv("RTC_STAY_MIN")) : 0u;
         params.stay_min = stay_env ? stay_env : RTC_STAY_MIN;

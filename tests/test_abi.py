@@ -63,7 +63,7 @@ int main(void) {
            sizeof(rtc_scene_info), sizeof(rtc_item_info), sizeof(rtc_light_info), sizeof(rtc_obj_info),
            offsetof(rtc_stats, kernel_ms));
     printf("%zu %zu %zu %zu\\n", offsetof(rtc_render_opts, exchange), offsetof(rtc_render_opts, fp_mode),
-           offsetof(rtc_stats, shadow_rays_skipped), offsetof(rtc_render_opts, tail_waves));
+           offsetof(rtc_stats, shadow_rays_skipped), offsetof(rtc_render_opts, tail_polls));
     return 0;
 }
 ''')
@@ -75,4 +75,4 @@ int main(void) {
                      ctypes.sizeof(N.SceneInfo), ctypes.sizeof(N.ItemInfo), ctypes.sizeof(N.LightInfo),
                      ctypes.sizeof(N.ObjInfo), N.Stats.kernel_ms.offset]
     assert [int(x) for x in b.split()] == [N.RenderOpts.exchange.offset, N.RenderOpts.fp_mode.offset,
-                                           N.Stats.shadow_rays_skipped.offset, N.RenderOpts.tail_waves.offset]
+                                           N.Stats.shadow_rays_skipped.offset, N.RenderOpts.tail_polls.offset]

@@ -288,9 +288,9 @@ def test_alternating_shares_on_a_side_stream_keep_their_own_tile_order():
         scene.close()
 
 
-def test_frames_in_flight_on_two_streams_with_tail_waves():
-    # rtc_render_opts.tail_waves: at the end of a frame of the persistent schedule only N waves stay to take over rays of
-    # others, the rest leave -- so that the next frame's grid (another scene handle = another work buffer, another stream)
+def test_frames_in_flight_on_two_streams_with_tail_polls():
+    # rtc_render_opts.tail_polls: at the end of a frame of the persistent schedule a wave without work looks N times for
+    # rays of others and then leaves -- so that the next frame's grid (another scene handle = another work buffer, another stream)
     # moves in while the last ray trees finish.  Six frames alternate between two handles and two streams without a
     # synchronisation; every canvas must be the frame itself (the parts of split pixels are added in another order).
     import torch
@@ -298,13 +298,13 @@ def test_frames_in_flight_on_two_streams_with_tail_waves():
     a, b = cam.compile(world, device=0), cam.compile(world, device=0)
     try:
         want = a.render(schedule=2, exchange=1)
-        lone = a.render(schedule=2, tail_waves=8)  # a frame alone: slower, same pixels
+        lone = a.render(schedule=2, tail_polls=8)  # a frame alone: slower, same pixels
         assert float(np.max(np.abs(lone - want))) < 1e-12
         streams = [torch.cuda.Stream(device="cuda:0") for _ in range(2)]
         bufs = [torch.full((cam.vsize, cam.hsize, 3), float("nan"), dtype=torch.float64, device="cuda:0") for _ in range(6)]
         torch.cuda.synchronize()
         for i, buf in enumerate(bufs):
-            (a, b)[i % 2].render_device(buf.data_ptr(), streams[i % 2].cuda_stream, schedule=2, tail_waves=8)
+            (a, b)[i % 2].render_device(buf.data_ptr(), streams[i % 2].cuda_stream, schedule=2, tail_polls=8)
         torch.cuda.synchronize()
         a.check()
         b.check()

@@ -1,6 +1,6 @@
 """Frames in flight: K frames of the stress scene launched back to back on ONE stream against the same K frames
-alternating between TWO scenes / streams / canvases, with RTC_TAIL_WAVES (waves that may wait for rays of others at the
-end of a frame; the rest leave and free their slots for the next frame's grid).
+alternating between TWO scenes / streams / canvases, with RTC_TAIL_POLLS (how often a wave without work looks for rays of
+others before it leaves and frees its slot for the next frame's grid; 0 = it stays until the frame ends).
 Usage: tools/pipeline_probe.py [w h frames] [tile_count]"""
 import importlib, os, sys, time
 import torch
@@ -27,16 +27,16 @@ def run(n_streams, frames):
     return 1e3 * (time.perf_counter() - t0) / frames
 
 
-for cap in ("0", "4096", "1024", "256", "64", "16"):
-    os.environ["RTC_TAIL_WAVES"] = cap
+for cap in ("0", "4096", "512", "128", "32", "8", "2"):
+    os.environ["RTC_TAIL_POLLS"] = cap
     run(1, 1)
     one = run(1, K)
     two = run(2, K)
     ref = bufs[0].clone()
-    os.environ["RTC_TAIL_WAVES"] = "0"
+    os.environ["RTC_TAIL_POLLS"] = "0"
     run(1, 1)
     d = float((bufs[0] - ref).abs().max())
     for s in scenes:
         s.check()
-    print("share %d/%d cap %5s: one stream %.1f ms/frame, two streams %.1f ms/frame  (max |delta| vs uncapped frame %.1e)"
+    print("share %d/%d polls %5s: one stream %.1f ms/frame, two streams %.1f ms/frame  (max |delta| vs uncapped frame %.1e)"
           % (1, tc, cap, one, two, d), flush=True)
