@@ -46,6 +46,14 @@ struct Node {
     std::vector<Node> seq;
     std::vector<std::pair<std::string, Node>> map;  // insertion order; lookups take the first match
 
+    // serde_yaml 0.9 (the reference pins 0.9.21, parse_scene/Cargo.toml:9) refuses a mapping that names a key twice
+    // (its Mapping visitor: "duplicate entry with key ..."), so parse_scene fails with ParseError::Yaml
+    void insert(const std::string &key, Node v, int line) {
+        for (const auto &kv : map)
+            if (kv.first == key)
+                fail("YAML deserialization error: duplicate entry with key \"" + key + "\" on line " + std::to_string(line));
+        map.emplace_back(key, std::move(v));
+    }
     const Node *get(const std::string &key) const {
         if (kind != MAP) return nullptr;
         for (const auto &kv : map)
@@ -234,7 +242,7 @@ struct Flow {
                     p++;
                     v = value();
                 }
-                n.map.emplace_back(key, v);
+                n.insert(key, v, line);
                 ws();
                 if (p < s.size() && s[p] == ',') p++;
             }
@@ -336,7 +344,7 @@ struct Yaml {
                 else if (i < lines.size() && lines[i].indent == indent && is_item(lines[i].text))
                     v = sequence(i, indent);  // "key:" followed by "- item" at the key's own indentation
             }
-            n.map.emplace_back(k, std::move(v));
+            n.insert(k, std::move(v), l.no);
         }
         if (i < lines.size() && lines[i].indent > indent)
             fail("YAML deserialization error: bad indentation on line " + std::to_string(lines[i].no));

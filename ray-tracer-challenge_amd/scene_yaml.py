@@ -26,7 +26,20 @@ class ParseError(ValueError):
 
 # --- a YAML 1.2 core-schema loader (serde_yaml 0.9 semantics): only true/false are booleans, `1e3` is a float
 class _CoreLoader(yaml.SafeLoader):
-    pass
+    def construct_mapping(self, node, deep=False):
+        # serde_yaml 0.9 (the reference pins 0.9.21, parse_scene/Cargo.toml:9) refuses a mapping that names a key twice
+        # ("duplicate entry with key ..."); PyYAML would keep the last one
+        seen = set()
+        for key_node, _ in node.value:
+            key = self.construct_object(key_node, deep=True)
+            try:
+                dup = key in seen
+                seen.add(key)
+            except TypeError:
+                dup = False
+            if dup:
+                raise yaml.constructor.ConstructorError(None, None, f"duplicate entry with key {key!r}", key_node.start_mark)
+        return super().construct_mapping(node, deep=deep)
 
 
 _CoreLoader.yaml_implicit_resolvers = {

@@ -1,0 +1,249 @@
+"""CPU: seeded random YAML scenes through BOTH loaders -- the C++ one behind the C ABI (rtc_scene_load_yaml,
+csrc/rtc_loader.cpp: an own parser for the YAML subset the reference's scenes use) and the Python mirror
+(scene_yaml.py over PyYAML with serde_yaml's core-schema rules).  Both restate parse_scene/src/lib.rs:118-784; here they
+must build the same tree -- transforms, materials, cylinder / cone limits, group order (nested groups first,
+lib.rs:677-712), `define` / `extend` (Q16), first definition of a name wins (lib.rs find()), lights, camera -- bit for
+bit, whatever the number spelling (integers, decimals, exponents, signs), flow-sequence spacing, comments and blank
+lines the generator throws in."""
+import numpy as np
+import pytest
+
+import test_cpp_loader as CL
+from scene_feed import rtc, SCENES
+
+
+def _num(rng, lo, hi, integers=0.3):
+    v = float(rng.uniform(lo, hi))
+    r = rng.random()
+    if r < integers:
+        return str(int(round(v)))
+    if r < 0.75:
+        return repr(round(v, int(rng.integers(1, 7))))
+    if r < 0.85:
+        return "%.*e" % (int(rng.integers(1, 6)), v)
+    if r < 0.92:
+        s = repr(round(v, 3))
+        return "+" + s if v >= 0 else s
+    return "%.3f" % v
+
+
+def _vec(rng, lo, hi, n=3):
+    sep = [", ", ",", " , ", ",  "][int(rng.integers(0, 4))]
+    pad = ["", " "][int(rng.integers(0, 2))]
+    return "[" + pad + sep.join(_num(rng, lo, hi) for _ in range(n)) + pad + "]"
+
+
+def _transform_item(rng, names):
+    r = rng.random()
+    if names and r < 0.25:
+        return names[int(rng.integers(0, len(names)))]
+    sep = [", ", ","][int(rng.integers(0, 2))]
+    if r < 0.5:
+        return "[" + sep.join(["scale"] + [_num(rng, 0.2, 3.0) for _ in range(3)]) + "]"
+    if r < 0.75:
+        return "[ " + sep.join(["translate"] + [_num(rng, -5.0, 5.0) for _ in range(3)]) + " ]"
+    return "[" + sep.join(["rotate-" + "xyz"[int(rng.integers(0, 3))], _num(rng, -3.2, 3.2, integers=0.1)]) + "]"
+
+
+def _material_lines(rng, indent):
+    keys = [("color", lambda: _vec(rng, 0.0, 1.0)), ("ambient", lambda: _num(rng, 0, 0.5)),
+            ("diffuse", lambda: _num(rng, 0, 1)), ("specular", lambda: _num(rng, 0, 1)),
+            ("shininess", lambda: _num(rng, 1, 400)), ("reflective", lambda: _num(rng, 0, 1)),
+            ("transparency", lambda: _num(rng, 0, 1)), ("refractive-index", lambda: _num(rng, 1, 2.5)),
+            ("casts-shadow", lambda: ["true", "false"][int(rng.integers(0, 2))])]
+    out = []
+    for k, f in keys:
+        if rng.random() < 0.45:
+            out.append(" " * indent + f"{k}: {f()}")
+    if not out:
+        out.append(" " * indent + "diffuse: " + _num(rng, 0, 1))
+    return out
+
+
+def _object_lines(rng, indent, mats, trs, level=0):
+    pad = " " * indent
+    kinds = ["sphere", "plane", "cube", "cylinder", "cone"] + (["group"] * 2 if level < 3 else [])
+    kind = kinds[int(rng.integers(0, len(kinds)))]
+    out = [pad + "- add: " + kind]
+    body = " " * (indent + 2)
+    if rng.random() < 0.2:
+        out.append(body + "# " + "a comment with: colons, [brackets] and - dashes")
+    if rng.random() < 0.7:
+        if mats and rng.random() < 0.4:
+            out.append(body + "material: " + mats[int(rng.integers(0, len(mats)))])
+        else:
+            out.append(body + "material:")
+            out += _material_lines(rng, indent + 4)
+    if rng.random() < 0.8:
+        out.append(body + "transform:")
+        for _ in range(int(rng.integers(1, 5))):
+            out.append(body + "  - " + _transform_item(rng, trs))
+    if kind in ("cylinder", "cone"):
+        if rng.random() < 0.7:
+            out.append(body + ["min", "minimum"][1] + ": " + _num(rng, -2, 0))
+        if rng.random() < 0.7:
+            out.append(body + "maximum: " + _num(rng, 0, 2))
+        if rng.random() < 0.6:
+            out.append(body + "closed: " + ["true", "false"][int(rng.integers(0, 2))])
+    if kind == "group":
+        out.append(body + "children:")
+        for _ in range(int(rng.integers(1, 5))):
+            out += _object_lines(rng, indent + 4, mats, trs, level + 1)
+    if rng.random() < 0.15:
+        out.append("")
+    return out
+
+
+def random_yaml(seed):
+    rng = np.random.default_rng(seed)
+    lines = ["# scene %d" % seed, "- add: camera", "  width: %d" % rng.integers(16, 400),
+             "  height: %d" % rng.integers(16, 300), "  field-of-view: " + _num(rng, 0.3, 1.6, integers=0.0),
+             "  from: " + _vec(rng, -10, 10), "  to: " + _vec(rng, -2, 2), "  up: [0, 1, 0]", ""]
+    for _ in range(int(rng.integers(1, 4))):
+        if rng.random() < 0.3:
+            lines += ["- add: area-light", "  corner: " + _vec(rng, -5, 5), "  full_uvec: " + _vec(rng, 0, 2),
+                      "  usteps: %d" % rng.integers(1, 5), "  full_vvec: " + _vec(rng, 0, 2),
+                      "  vsteps: %d" % rng.integers(1, 5), "  intensity: " + _vec(rng, 0.1, 1.5)]
+        else:
+            lines += ["- add: light", "  at: " + _vec(rng, -20, 20), "  intensity: " + _vec(rng, 0.1, 1.0)]
+    mats, trs = [], []
+    for k in range(int(rng.integers(0, 6))):
+        if rng.random() < 0.5:
+            name = "mat-%d" % (k if rng.random() < 0.85 or not mats else 0)  # (sometimes a name that is taken: the first wins)
+            lines.append("- define: " + name)
+            if mats and rng.random() < 0.5:
+                lines.append("  extend: " + mats[int(rng.integers(0, len(mats)))])
+            lines.append("  value:")
+            lines += _material_lines(rng, 4)
+            if name not in mats:
+                mats.append(name)
+        else:
+            name = "tr-%d" % k
+            lines += ["- define: " + name, "  value:"]
+            for _ in range(int(rng.integers(1, 4))):
+                lines.append("    - " + _transform_item(rng, trs))
+            trs.append(name)
+        if rng.random() < 0.3:
+            lines.append("")
+    for _ in range(int(rng.integers(1, 9))):
+        lines += _object_lines(rng, 0, mats, trs)
+    if rng.random() < 0.3:
+        lines += ["- add: obj", "  file: obj/triangles.obj", "  transform:", "    - " + _transform_item(rng, trs)]
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed", list(range(200)))
+def test_both_loaders_build_the_same_tree(seed):
+    text = random_yaml(seed)
+    nat = rtc.NativeScene.from_yaml(text, base_dir=SCENES)
+    try:
+        py = rtc.parse_scene(text, base_dir=SCENES)
+        a, b = [], []
+        CL._walk_native(nat, -1, a)
+        CL._walk_python(py.objects, b)
+        assert len(a) == len(b), text
+        for x, y in zip(a, b):
+            assert x == y, text
+        cam = nat.camera()
+        assert (cam["hsize"], cam["vsize"], cam["field_of_view"]) == (py.camera.hsize, py.camera.vsize, py.camera.field_of_view)
+        assert np.array_equal(cam["view"], py.camera.transformation.m)
+        nl = nat.lights()
+        assert len(nl) == len(py.lights)
+        for x, y in zip(nl, py.lights):
+            if isinstance(y, rtc.AreaLight):
+                assert x["is_area"] == 1 and x["usteps"] == y.usteps and x["vsteps"] == y.vsteps, text
+                assert x["intensity"] == list(map(float, y.intensity)) and x["corner"] == list(map(float, y.corner)), text
+                # AreaLight::new, light.rs:80-104: uvec = full_uvec / usteps
+                assert x["uvec"] == [float(c) / y.usteps for c in y.full_uvec], text
+                assert x["vvec"] == [float(c) / y.vsteps for c in y.full_vvec], text
+            else:
+                assert x["position"] == list(map(float, y.position)) and x["intensity"] == list(map(float, y.intensity))
+    finally:
+        nat.close()
+
+
+def _mutate(text, seed):
+    """one damaged line: deleted, its ':' / '[' / ']' / ',' removed, indented one more or two less"""
+    rng = np.random.default_rng(seed + 9999)
+    lines = text.split("\n")
+    k = int(rng.integers(1, len(lines) - 1))
+    mode = int(rng.integers(0, 7))
+    if mode == 0:
+        del lines[k]
+    elif mode == 1:
+        lines[k] = lines[k].replace(":", "", 1)
+    elif mode == 2:
+        lines[k] = lines[k].replace("[", "", 1)
+    elif mode == 3:
+        lines[k] = " " + lines[k]
+    elif mode == 4:
+        lines[k] = lines[k].replace("]", "", 1)
+    elif mode == 5:
+        lines[k] = lines[k].replace(",", " ", 1)
+    elif lines[k].startswith("  "):
+        lines[k] = lines[k][2:]
+    return "\n".join(lines)
+
+
+@pytest.mark.parametrize("block", range(10))
+def test_both_loaders_agree_on_damaged_scenes(block):
+    # 60 damaged scenes per block: both loaders refuse, or both accept and build the same tree (about half of each)
+    accepted = refused = 0
+    for seed in range(60 * block, 60 * block + 60):
+        text = _mutate(random_yaml(seed % 200), seed)
+        nat = py = None
+        try:
+            nat = rtc.NativeScene.from_yaml(text, base_dir=SCENES)
+        except rtc.RtcError:
+            pass
+        try:
+            py = rtc.parse_scene(text, base_dir=SCENES)
+        except rtc.ParseError:
+            pass
+        try:
+            assert (nat is None) == (py is None), text
+            if nat is not None:
+                a, b = [], []
+                CL._walk_native(nat, -1, a)
+                CL._walk_python(py.objects, b)
+                assert a == b, text
+                accepted += 1
+            else:
+                refused += 1
+        finally:
+            if nat is not None:
+                nat.close()
+    assert accepted > 5 and refused > 5
+
+
+DUPLICATE = """
+- add: camera
+  width: 10
+  height: 10
+  field-of-view: 1
+  from: [0, 0, -5]
+  to: [0, 0, 0]
+  up: [0, 1, 0]
+- add: sphere
+  material:
+    color: [1, 0, 0]
+  transform:
+    - [scale, 2, 2, 2]
+  material:
+    color: [0, 1, 0]
+"""
+
+
+def test_a_key_named_twice_is_refused_by_both_loaders():
+    # serde_yaml 0.9 (parse_scene/Cargo.toml:9 pins 0.9.21) fails on a mapping that names a key twice ("duplicate entry
+    # with key"), so parse_scene returns ParseError::Yaml; found by the damaged-scene fuzz above, where the C++ parser
+    # kept the first `material:` and PyYAML the last
+    with pytest.raises(rtc.RtcError) as e:
+        rtc.NativeScene.from_yaml(DUPLICATE)
+    assert "duplicate entry with key" in str(e.value)
+    with pytest.raises(rtc.ParseError) as e:
+        rtc.parse_scene(DUPLICATE)
+    assert "duplicate entry with key" in str(e.value)
+    with pytest.raises(rtc.RtcError):
+        rtc.NativeScene.from_yaml(DUPLICATE.replace("  material:\n    color: [0, 1, 0]\n", "  material: {color: [0, 1, 0], color: [1, 1, 1]}\n")
+                                  .replace("  material:\n    color: [1, 0, 0]\n", ""))
