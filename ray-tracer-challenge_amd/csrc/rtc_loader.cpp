@@ -139,6 +139,17 @@ bool match_float(const std::string &s) {
     return k == s.size();
 }
 
+// the strings Rust's f64::from_str accepts: [+-]? ( inf | infinity | nan, ASCII case-insensitive | decimal ), decimal =
+// digits [. digits*] [exp] | . digits [exp], exp = [eE] [+-]? digits
+bool rust_f64_syntax(const std::string &s) {
+    size_t k = 0;
+    if (k < s.size() && (s[k] == '-' || s[k] == '+')) k++;
+    std::string low;
+    for (size_t q = k; q < s.size(); q++) low.push_back((char)tolower((unsigned char)s[q]));
+    if (low == "inf" || low == "infinity" || low == "nan") return true;
+    return k < s.size() && match_float(s.substr(k));
+}
+
 Node scalar(const std::string &raw) {
     Node n;
     const std::string s = trim(raw);
@@ -570,10 +581,11 @@ void add_obj(rtc_scene *scene, const std::string &text, const Mat4 &transform, i
             if (tok.size() < 4) continue;  // "Malformed vertex record" is printed and the line skipped (:122-124)
             double c[3];
             for (int k = 0; k < 3; k++) {
-                char *endp = nullptr;
-                c[k] = strtod(tok[1 + k].c_str(), &endp);
-                if (endp == tok[1 + k].c_str() || *endp)
+                // f64::from_str (obj_file/src/lib.rs:82-96 `.parse::<f64>()`): ASCII decimal syntax or inf / infinity /
+                // nan in any case -- strtod alone would also take hexadecimal floats and "nan(...)"
+                if (!rust_f64_syntax(tok[1 + k]))
                     fail("invalid input: Invalid vertex record on line " + std::to_string(line_no) + ": " + tok[1 + k]);
+                c[k] = strtod(tok[1 + k].c_str(), nullptr);
             }
             (tok[0] == "v" ? vertices : normals).push_back({c[0], c[1], c[2]});
         } else if (tok[0] == "f") {

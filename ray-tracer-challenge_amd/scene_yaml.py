@@ -409,11 +409,14 @@ class _MeshBuilder:
             self.nrm.append([*normals[0], *normals[1], *normals[2]])
 
 
+# the strings Rust's f64::from_str accepts (Python's float() also takes "1_0" and non-ASCII digits)
+_RUST_F64 = re.compile(r"[+-]?(?:(?i:inf|infinity|nan)|(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?)", re.ASCII)
+
+
 def _parse_f64(tok, line_no):
-    try:
-        return float(tok)
-    except ValueError:
+    if not _RUST_F64.fullmatch(tok):
         raise ParseError(f"invalid input: Invalid vertex record on line {line_no}: {tok}")
+    return float(tok)
 
 
 def _parse_usize(tok, what, line_no):

@@ -247,3 +247,122 @@ def test_a_key_named_twice_is_refused_by_both_loaders():
     with pytest.raises(rtc.RtcError):
         rtc.NativeScene.from_yaml(DUPLICATE.replace("  material:\n    color: [0, 1, 0]\n", "  material: {color: [0, 1, 0], color: [1, 1, 1]}\n")
                                   .replace("  material:\n    color: [1, 0, 0]\n", ""))
+
+
+# ----------------------------------------------------------------------------------------------- obj_file
+
+_NUMS = ["1", "-1", "0.5", "-2.25", "1e2", "1.5E-1", "+3", ".5", "5.", "1_0", "0x10", "inf", "-inf", "nan", "NaN",
+         "Infinity", "1e", "--1", "1.2.3", "1,5", "١", "1e+2", "-.5e1", "1d2", "0x1p3", "1f"]
+
+
+def random_obj(seed):
+    """vertices, normals, faces in every index form (v, v//n, v/t/n, v/t), polygons (fans, Q11), named groups, ignored
+    records; every second file also holds records that must be refused (bad numbers, indices out of range, too few
+    vertices, an unnamed group)"""
+    rng = np.random.default_rng(seed)
+    exotic = rng.random() < 0.5
+
+    def num():
+        if exotic and rng.random() < 0.08:
+            return _NUMS[int(rng.integers(0, len(_NUMS)))]
+        return _NUMS[int(rng.integers(0, 8))] if rng.random() < 0.5 else repr(round(float(rng.uniform(-3, 3)), 3))
+
+    lines = []
+    nv, nn = int(rng.integers(3, 12)), int(rng.integers(0, 6))
+    for _ in range(nv):
+        lines.append("v " + " ".join(num() for _ in range(3 if rng.random() < 0.9 else int(rng.integers(1, 5)))))
+    for _ in range(nn):
+        lines.append("vn " + " ".join(num() for _ in range(3)))
+    for _ in range(int(rng.integers(1, 10))):
+        r = rng.random()
+        if r < 0.1:
+            lines.append("g " + ["First", "Second", "First", ""][int(rng.integers(0, 4))])
+        elif r < 0.15:
+            lines.append(["# comment", "vt 0 1", "s off", "usemtl x", "", "   "][int(rng.integers(0, 6))])
+        else:
+            toks, mode = [], int(rng.integers(0, 4))
+            for _ in range(int(rng.integers(1 if exotic else 3, 7))):
+                vi = int(rng.integers(0 if exotic else 1, nv + (2 if exotic else 1)))
+                ni = int(rng.integers(0 if exotic else 1, max(nn, 1) + (2 if exotic else 1)))
+                if mode == 0 or (nn == 0 and not exotic):
+                    toks.append(str(vi))
+                elif mode == 1:
+                    toks.append(f"{vi}//{ni}")
+                elif mode == 2:
+                    toks.append(f"{vi}/7/{ni}")
+                else:
+                    toks.append(f"{vi}/{ni}" if exotic else str(vi))
+            if exotic and rng.random() < 0.1:
+                toks[0] = ["+1", "-1", "1.0", "a", "1/", "/1", "1//"][int(rng.integers(0, 7))]
+            lines.append("f " + " ".join(toks))
+    return "\n".join(lines) + "\n"
+
+
+def _obj_native(sc, parent, out):
+    for c in sc.children(parent):
+        if sc.item(c)["kind"] == CL.GROUP:
+            out.append("group")
+            _obj_native(sc, c, out)
+            out.append("end")
+        else:
+            pts, nrm = sc.triangles(c)
+            out.append((pts.tobytes(), None if nrm is None else nrm.tobytes()))
+
+
+def _obj_python(objs, out):
+    for o in objs:
+        if isinstance(o, rtc.Group):
+            out.append("group")
+            _obj_python(o.children, out)
+            out.append("end")
+        else:
+            pts = np.ascontiguousarray(o.points, dtype=np.float64).reshape(-1, 9)
+            nrm = None if o.normals is None else np.ascontiguousarray(o.normals, dtype=np.float64).reshape(-1, 9)
+            out.append((pts.tobytes(), None if nrm is None else nrm.tobytes()))
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_both_obj_loaders_agree(block):
+    accepted = refused = 0
+    for seed in range(100 * block, 100 * block + 100):
+        text = random_obj(seed)
+        sc = po = None
+        try:
+            sc, _ = rtc.NativeScene.from_obj(text)
+        except rtc.RtcError:
+            pass
+        try:
+            po = rtc.parse_obj_string(text)
+        except rtc.ParseError:
+            pass
+        try:
+            assert (sc is None) == (po is None), text
+            if sc is not None:
+                a, b = [], []
+                _obj_native(sc, -1, a)
+                _obj_python([po.default_group], b)
+                assert a == b, text
+                accepted += 1
+            else:
+                refused += 1
+        finally:
+            if sc is not None:
+                sc.close()
+    assert accepted > 10 and refused > 10
+
+
+@pytest.mark.parametrize("tok,ok", [("1", True), ("+3", True), (".5", True), ("5.", True), ("1.5E-1", True), ("-.5e1", True),
+                                    ("inf", True), ("-Infinity", True), ("NaN", True), ("1_0", False), ("0x10", False),
+                                    ("0x1p3", False), ("١", False), ("1e", False), ("1d2", False), ("1,5", False),
+                                    ("nan(1)", False), ("infinit", False), (".", False), ("+", False)])
+def test_vertex_numbers_follow_rust_f64_from_str(tok, ok):
+    # obj_file/src/lib.rs:82-96 parses coordinates with str::parse::<f64>(): ASCII decimal syntax, or inf / infinity /
+    # nan in any case.  (strtod would also take hexadecimal floats, Python's float() "1_0" and non-ASCII digits: found by
+    # the fuzz above.)
+    text = f"v {tok} 0 0\n"
+    for load, err in ((lambda: rtc.NativeScene.from_obj(text)[0].close(), rtc.RtcError), (lambda: rtc.parse_obj_string(text), rtc.ParseError)):
+        if ok:
+            load()
+        else:
+            with pytest.raises(err):
+                load()
