@@ -16,7 +16,7 @@ for name, path in libs:
     if path:
         env["RTC_AMD_LIB"] = path
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", steps, "--warmup", "2", "--extra",
-                        "--no-cpu-baseline --no-pipelined", "--no-flavours", "--workload", "teapot_4k"], env=env, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--no-pipelined", "--no-flavours", "--workload", "teapot_4k"], env=env, capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         print(name, "FAILED", r.stderr[-500:])
         continue
