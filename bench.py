@@ -260,11 +260,12 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": ("synthetic stress scene (stress_scene.py, seed 0x5EED1234)" if args.workload == "stress_4k" else
+        "data": ("synthetic stress scene (stress_scene.py, seed 0x5EED1234)" if WORKLOADS[args.workload][0] == "stress" else
                  "reference sample scene (scenes/%s.yaml, camera resized)" % WORKLOADS[args.workload][0]),
         "config": {
-            "workload": "%s: scenes/%s.yaml at %dx%d, depth 5, %d active pixels" % (
-                args.workload, WORKLOADS[args.workload][0], hsize, vsize, (hsize - 1) * (vsize - 1)),
+            "workload": "%s: %s at %dx%d, depth 5, %d active pixels" % (
+                args.workload, "stress_scene.py (100 000 glass / mirror spheres + teapot mesh)" if WORKLOADS[args.workload][0] == "stress"
+                else "scenes/%s.yaml" % WORKLOADS[args.workload][0], hsize, vsize, (hsize - 1) * (vsize - 1)),
             "sharding": "interleaved %d-row tiles over %d rank(s); RCCL gather to rank 0" % (TILE_ROWS, world_size)
             if distributed else "single GPU, whole frame in one launch",
             "fp_mode": "strict (no FMA contraction: the reference's arithmetic; there is no other flavour)",
