@@ -7,6 +7,7 @@
 // Q14 (a `material:` on a YAML group is parsed, then dropped), Q16 (`extend` overrides only present keys;
 // transform lists left-multiply in list order).
 #include <cctype>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -35,7 +36,7 @@ struct ParseFail {
 // ------------------------------------------------------------------------------------------------
 // A YAML subset sufficient for scene files (what serde_yaml::from_str::<Sequence> is asked to read there):
 // block sequences and mappings nested by indentation, flow sequences / mappings, comments, plain and quoted
-// scalars resolved with the YAML 1.2 core schema (only true/false are booleans; integers and floats are numbers).
+// scalars typed like serde_yaml 0.9 types them (see scalar()).
 // ------------------------------------------------------------------------------------------------
 struct Node {
     enum Kind { NUL, BOOL, INT, FLOAT, STR, SEQ, MAP } kind = NUL;
@@ -150,6 +151,19 @@ bool rust_f64_syntax(const std::string &s) {
     return k < s.size() && match_float(s.substr(k));
 }
 
+// serde_yaml 0.9: an integer spelt with leading zeros is a string (de.rs digits_but_not_number)
+bool digits_but_not_number(const std::string &v) {
+    const std::string t = (!v.empty() && (v[0] == '-' || v[0] == '+')) ? v.substr(1) : v;
+    if (t.size() < 2 || t[0] != '0') return false;
+    for (size_t k = 1; k < t.size(); k++)
+        if (!isdigit((unsigned char)t[k])) return false;
+    return true;
+}
+
+// Plain scalars are typed the way serde_yaml 0.9 types them (de.rs visit_untagged_scalar; the reference pins 0.9.21,
+// parse_scene/Cargo.toml:9 -- the crate is not vendored, these rules restate its published source: parity unpinned):
+// null; true / false; integers (decimal, 0x / 0o / 0b, optional sign first; leading zeros make a string; beyond 64 bits:
+// the float rule); floats (.inf / -.inf / .nan, else f64::from_str after an optional "+" if the value is finite); string.
 Node scalar(const std::string &raw) {
     Node n;
     const std::string s = trim(raw);
@@ -164,26 +178,62 @@ Node scalar(const std::string &raw) {
         n.b = (s[0] == 't' || s[0] == 'T');
         return n;
     }
-    if (match_int(s)) {
-        n.kind = Node::INT;
-        n.i = strtoll(s.c_str(), nullptr, 10);
-        return n;
+    {
+        const bool neg = s[0] == '-';
+        const std::string body = (s[0] == '-' || s[0] == '+') ? s.substr(1) : s;
+        if (!body.empty() && body[0] != '-' && body[0] != '+') {
+            int radix = 10;
+            std::string digits = body;
+            if (body.compare(0, 2, "0x") == 0) radix = 16, digits = body.substr(2);
+            else if (body.compare(0, 2, "0o") == 0) radix = 8, digits = body.substr(2);
+            else if (body.compare(0, 2, "0b") == 0) radix = 2, digits = body.substr(2);
+            bool ok = !digits.empty() && (radix != 10 || !digits_but_not_number(s));
+            for (char c : digits) {
+                const int d = isdigit((unsigned char)c) ? c - '0' : isxdigit((unsigned char)c) ? tolower((unsigned char)c) - 'a' + 10 : 99;
+                ok = ok && d < radix;
+            }
+            if (ok) {
+                errno = 0;
+                const unsigned long long u = strtoull(digits.c_str(), nullptr, radix);
+                // i64 for negative values, u64 for the others (serde_yaml tries u64, then i64); beyond: the float rule
+                if (errno == 0 && (!neg || u <= (1ull << 63))) {
+                    n.kind = Node::INT;
+                    if (neg) {
+                        n.i = (long long)(0ull - u);
+                    } else if (u <= (unsigned long long)std::numeric_limits<long long>::max()) {
+                        n.i = (long long)u;
+                    } else {
+                        n.kind = Node::FLOAT;  // (a u64 above i64::MAX: Value::as_f64 of it; nothing here reads such an integer)
+                        n.f = (double)u;
+                    }
+                    return n;
+                }
+            }
+        }
     }
-    if (match_float(s)) {
-        n.kind = Node::FLOAT;
-        n.f = strtod(s.c_str(), nullptr);
-        return n;
-    }
-    const std::string t = (s[0] == '-' || s[0] == '+') ? s.substr(1) : s;
-    if (t == ".inf" || t == ".Inf" || t == ".INF") {
-        n.kind = Node::FLOAT;
-        n.f = (s[0] == '-') ? -std::numeric_limits<double>::infinity() : std::numeric_limits<double>::infinity();
-        return n;
-    }
-    if (s == ".nan" || s == ".NaN" || s == ".NAN") {
-        n.kind = Node::FLOAT;
-        n.f = std::numeric_limits<double>::quiet_NaN();
-        return n;
+    if (!digits_but_not_number(s)) {
+        const std::string unpositive = s[0] == '+' ? s.substr(1) : s;
+        const bool double_sign = s[0] == '+' && !unpositive.empty() && (unpositive[0] == '-' || unpositive[0] == '+');
+        if (!double_sign) {
+            if (unpositive == ".inf" || unpositive == ".Inf" || unpositive == ".INF" || s == "-.inf" || s == "-.Inf" || s == "-.INF") {
+                n.kind = Node::FLOAT;
+                n.f = (s[0] == '-') ? -std::numeric_limits<double>::infinity() : std::numeric_limits<double>::infinity();
+                return n;
+            }
+            if (s == ".nan" || s == ".NaN" || s == ".NAN") {
+                n.kind = Node::FLOAT;
+                n.f = std::numeric_limits<double>::quiet_NaN();
+                return n;
+            }
+            if (rust_f64_syntax(unpositive)) {
+                const double f = strtod(unpositive.c_str(), nullptr);
+                if (std::isfinite(f)) {
+                    n.kind = Node::FLOAT;
+                    n.f = f;
+                    return n;
+                }
+            }
+        }
     }
     n.kind = Node::STR;
     n.s = s;

@@ -24,7 +24,7 @@ class ParseError(ValueError):
     """parse_scene::ParseError / obj_file::ParserError"""
 
 
-# --- a YAML 1.2 core-schema loader (serde_yaml 0.9 semantics): only true/false are booleans, `1e3` is a float
+# --- a loader with serde_yaml 0.9's scalar typing (below): only true/false are booleans, `1e3` is a float, `0x10` is 16
 class _CoreLoader(yaml.SafeLoader):
     def construct_mapping(self, node, deep=False):
         # serde_yaml 0.9 (the reference pins 0.9.21, parse_scene/Cargo.toml:9) refuses a mapping that names a key twice
@@ -42,18 +42,71 @@ class _CoreLoader(yaml.SafeLoader):
         return super().construct_mapping(node, deep=deep)
 
 
-_CoreLoader.yaml_implicit_resolvers = {
-    k: [(tag, rx) for tag, rx in v if tag not in ("tag:yaml.org,2002:bool", "tag:yaml.org,2002:float",
-                                                  "tag:yaml.org,2002:int", "tag:yaml.org,2002:timestamp")]
-    for k, v in yaml.SafeLoader.yaml_implicit_resolvers.items()
-}
-_CoreLoader.add_implicit_resolver("tag:yaml.org,2002:bool", re.compile(r"^(?:true|True|TRUE|false|False|FALSE)$"),
-                                  list("tTfF"))
-_CoreLoader.add_implicit_resolver("tag:yaml.org,2002:int", re.compile(r"^[-+]?[0-9]+$"), list("-+0123456789"))
-_CoreLoader.add_implicit_resolver(
-    "tag:yaml.org,2002:float",
-    re.compile(r"^(?:[-+]?(?:\.[0-9]+|[0-9]+(?:\.[0-9]*)?)(?:[eE][-+]?[0-9]+)?|[-+]?\.(?:inf|Inf|INF)|\.(?:nan|NaN|NAN))$"),
-    list("-+0123456789."))
+# Plain scalars are typed the way serde_yaml 0.9 types them (de.rs, visit_untagged_scalar; the reference pins 0.9.21,
+# parse_scene/Cargo.toml:9 -- the crate is not vendored, the rules below restate its published source: parity unpinned):
+#   null: "", ~, null, Null, NULL;  bool: true / false in the three spellings;
+#   integers: decimal with an optional sign, 0x / 0o / 0b with an optional sign before the prefix; an integer spelt with
+#   leading zeros ("007") is a STRING (digits_but_not_number); integers beyond 64 bits fall through to the float rule;
+#   floats: .inf / -.inf / .nan in the three spellings, else whatever Rust's f64::from_str accepts after an optional
+#   "+", provided the value is FINITE ("inf", "nan", "1e999" stay strings);  everything else: a string.
+_CoreLoader.yaml_implicit_resolvers = {}
+_DEC = re.compile(r"[0-9]+", re.ASCII)
+_RADIX = {"0x": (16, re.compile(r"[0-9a-fA-F]+", re.ASCII)), "0o": (8, re.compile(r"[0-7]+", re.ASCII)),
+          "0b": (2, re.compile(r"[01]+", re.ASCII))}
+_RUST_F64_PLAIN = re.compile(r"[+-]?(?:(?i:inf|infinity|nan)|(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?)", re.ASCII)
+
+
+def _digits_but_not_number(v):
+    t = v[1:] if v[:1] in ("-", "+") else v
+    return len(t) > 1 and t[0] == "0" and t[1:].isascii() and t[1:].isdigit()
+
+
+def _serde_int(v):
+    neg = v.startswith("-")
+    body = v[1:] if v[:1] in ("-", "+") else v
+    if body[:1] in ("-", "+"):
+        return None
+    for prefix, (radix, rx) in _RADIX.items():
+        if body.startswith(prefix) and rx.fullmatch(body[2:]):
+            return -int(body[2:], radix) if neg else int(body[2:], radix)
+    if _digits_but_not_number(v) or not _DEC.fullmatch(body):
+        return None
+    return -int(body) if neg else int(body)
+
+
+def _serde_scalar(v):
+    if v in ("", "~", "null", "Null", "NULL"):
+        return None
+    if v in ("true", "True", "TRUE"):
+        return True
+    if v in ("false", "False", "FALSE"):
+        return False
+    i = _serde_int(v)
+    if i is not None and -(1 << 63) <= i < (1 << 64):
+        return i
+    if not _digits_but_not_number(v):
+        unpositive = v[1:] if v.startswith("+") else v
+        if v.startswith("+") and unpositive[:1] in ("-", "+"):
+            return v
+        if unpositive in (".inf", ".Inf", ".INF"):
+            return INF
+        if v in ("-.inf", "-.Inf", "-.INF"):
+            return -INF
+        if v in (".nan", ".NaN", ".NAN"):
+            return float("nan")
+        if _RUST_F64_PLAIN.fullmatch(unpositive):
+            f = float(unpositive)
+            if f == f and f not in (INF, -INF):
+                return f
+    return v
+
+
+def _construct_plain(loader, node):
+    v = loader.construct_scalar(node)
+    return _serde_scalar(v) if node.style is None else v
+
+
+_CoreLoader.add_constructor("tag:yaml.org,2002:str", _construct_plain)
 
 
 def _as_f64(v):

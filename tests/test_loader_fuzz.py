@@ -366,3 +366,48 @@ def test_vertex_numbers_follow_rust_f64_from_str(tok, ok):
         else:
             with pytest.raises(err):
                 load()
+
+
+# ----------------------------------------------------------------------------------------------- scalar typing
+
+_CAM = """
+- add: camera
+  width: 10
+  height: 10
+  field-of-view: 1
+  from: [0, 0, -5]
+  to: [0, 0, 0]
+  up: [0, 1, 0]
+"""
+
+# spelling -> the number serde_yaml 0.9 reads (None: it reads a STRING, and parse_scene's get_f64 refuses the scene)
+_SCALARS = [("3", 3.0), ("-3", -3.0), ("+3", 3.0), ("0", 0.0), ("-0", 0.0), ("0x10", 16.0), ("-0x10", -16.0), ("+0x1F", 31.0),
+            ("0o17", 15.0), ("0b101", 5.0), ("007", None), ("-012", None), ("00", None), ("0.5", 0.5), ("00.5", 0.5),
+            (".5", 0.5), ("5.", 5.0), ("+.5", 0.5), ("-.5e1", -5.0), ("1e3", 1000.0), ("1E+3", 1000.0), ("1e-2", 0.01),
+            ("1_000", None), ("0x1G", None), ("0b102", None), ("++1", None), ("+-1", None), ("1e", None), ("1e999", None),
+            ("inf", None), ("nan", None), ("Infinity", None), (".inf", float("inf")), ("+.inf", float("inf")),
+            ("-.INF", float("-inf")), ("18446744073709551615", 18446744073709551615.0),
+            ("99999999999999999999", 1e20), ("-9223372036854775808", -9223372036854775808.0), ("true", None), ("~", None),
+            ("'3'", None), ('"3"', None), ("three", None)]
+
+
+@pytest.mark.parametrize("spelling,value", _SCALARS)
+def test_plain_scalars_are_typed_like_serde_yaml_0_9(spelling, value):
+    # serde_yaml 0.9 de.rs (visit_untagged_scalar, parse_unsigned_int / parse_negative_int, digits_but_not_number,
+    # parse_f64), restated from its published source -- the crate is not vendored (parse_scene/Cargo.toml:9 pins
+    # 0.9.21): parity unpinned.  The number arrives as the x of a translation.
+    text = _CAM + f"- add: sphere\n  transform:\n    - [translate, {spelling}, 0, 0]\n"
+    if value is None:
+        with pytest.raises(rtc.RtcError):
+            rtc.NativeScene.from_yaml(text)
+        with pytest.raises(rtc.ParseError):
+            rtc.parse_scene(text)
+        return
+    nat = rtc.NativeScene.from_yaml(text)
+    try:
+        (obj,) = nat.children(-1)
+        a = nat.item(obj)["transform"]
+    finally:
+        nat.close()
+    b = np.asarray(rtc.parse_scene(text).objects[0].transformation.m)
+    assert a[0, 3] == value and b[0, 3] == value and np.array_equal(a, b, equal_nan=True)  # (inf * 0 in the product)
