@@ -27,7 +27,7 @@ def run(n_streams, frames):
     return 1e3 * (time.perf_counter() - t0) / frames
 
 
-for cap in ("0", "4096", "512", "128", "32", "8", "2"):
+for cap in (sys.argv[5].split(",") if len(sys.argv) > 5 else ("0", "4096", "512", "128", "32", "8", "2")):
     os.environ["RTC_TAIL_POLLS"] = cap
     run(1, 1)
     one = run(1, K)
