@@ -10,11 +10,12 @@ w, h, K = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv
 tc = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 world, cam = rtc.stress_scene.build(100000, w, h)
 dev = torch.device("cuda:0")
-scenes = [cam.compile(world, device=0) for _ in range(2)]
+NS = int(os.environ.get("PIPE_STREAMS", "2"))  # frames in flight of the second column
+scenes = [cam.compile(world, device=0) for _ in range(NS)]
 kw = dict(tile_rows=8, tile_index=0, tile_count=tc) if tc > 1 else {}
 rows = scenes[0].local_rows(**kw) if tc > 1 else h
-bufs = [torch.zeros((rows, w, 3), dtype=torch.float64, device=dev) for _ in range(2)]
-streams = [torch.cuda.Stream(dev) for _ in range(2)]
+bufs = [torch.zeros((rows, w, 3), dtype=torch.float64, device=dev) for _ in range(NS)]
+streams = [torch.cuda.Stream(dev) for _ in range(NS)]
 
 
 def run(n_streams, frames):
@@ -31,12 +32,12 @@ for cap in (sys.argv[5].split(",") if len(sys.argv) > 5 else ("0", "4096", "512"
     os.environ["RTC_TAIL_POLLS"] = cap
     run(1, 1)
     one = run(1, K)
-    two = run(2, K)
+    two = run(NS, K)
     ref = bufs[0].clone()
     os.environ["RTC_TAIL_POLLS"] = "0"
     run(1, 1)
     d = float((bufs[0] - ref).abs().max())
     for s in scenes:
         s.check()
-    print("share %d/%d polls %5s: one stream %.1f ms/frame, two streams %.1f ms/frame  (max |delta| vs uncapped frame %.1e)"
-          % (1, tc, cap, one, two, d), flush=True)
+    print("share %d/%d polls %5s: one stream %.1f ms/frame, %d streams %.1f ms/frame  (max |delta| vs uncapped frame %.1e)"
+          % (1, tc, cap, one, NS, two, d), flush=True)
