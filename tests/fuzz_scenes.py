@@ -128,15 +128,15 @@ def _group(rng, level=0):
     return g
 
 
-def random_scene(seed, w=120, h=80):
-    """(world, camera, depth) of seed"""
+def random_scene(seed, w=120, h=80, n_objects=None):
+    """(world, camera, depth) of seed; n_objects overrides the 3..13 top-level objects (tools/fuzz_hunt.py: larger scenes)"""
     rng = np.random.default_rng(seed)
     objs = []
     if rng.random() < 0.8:
         objs.append(rtc.Plane(material=_material(rng, glass_ok=False)))
     if rng.random() < 0.4:
         objs.append(rtc.Plane(M.rotation_x(math.pi / 2).translate(0, 0, float(rng.uniform(4, 8))), _material(rng, glass_ok=False)))
-    for _ in range(int(rng.integers(3, 14))):
+    for _ in range(int(rng.integers(3, 14)) if n_objects is None else n_objects):
         r = rng.random()
         if r < 0.6:
             objs.append(_leaf(rng))
@@ -146,6 +146,10 @@ def random_scene(seed, w=120, h=80):
             # the Csg node has no transformation of its own: wrap it in a group to place it
             objs.append(rtc.Group(transformation=_transform(rng, 2.5), children=[_csg(rng)]))
     n_lights = int(rng.integers(1, 4))
+    if n_objects is not None:
+        # the reference traces the secondary rays of a hit once per light and refraction keeps the bounce budget: a chain
+        # of k glass surfaces costs 2^k with two lights -- in a crowd of glass the oracle would not finish
+        n_lights = 1
     lights = []
     for k in range(n_lights):
         pos = (float(rng.uniform(-8, 8)), float(rng.uniform(4, 10)), float(rng.uniform(-9, -2)))

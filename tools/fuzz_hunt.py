@@ -1,5 +1,5 @@
 """Bug hunt beyond the committed seeds: random scenes of tests/fuzz_scenes.py, GPU (static whole tiles, default,
-persistent, linear scan) against the oracle.  Prints one line per seed that differs.  Usage: tools/fuzz_hunt.py first last"""
+persistent, linear scan) against the oracle.  Prints one line per seed that differs.  Usage: tools/fuzz_hunt.py first last [objects per scene]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -8,10 +8,12 @@ from scene_feed import rtc
 from fuzz_scenes import random_scene
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
+n_objects = int(sys.argv[3]) if len(sys.argv) > 3 else None
 bad = 0
 t0 = time.time()
+last_print = t0
 for seed in range(first, last + 1):
-    world, cam, depth = random_scene(seed)
+    world, cam, depth = random_scene(seed, n_objects=n_objects)
     ow = sf.to_oracle(world, cam)
     ref = ow.render(depth=depth)
     good = ~np.isnan(ref).any(axis=-1)
@@ -44,6 +46,7 @@ for seed in range(first, last + 1):
     if msgs:
         bad += 1
         print(f"seed {seed} ({int((~good).sum())} diverged pixels, depth {depth}, {len(world.lights)} lights): " + "; ".join(msgs), flush=True)
-    if seed % 20 == 0:
+    if seed % 20 == 0 or time.time() - last_print > 30:
+        last_print = time.time()
         print(f"... seed {seed}, {bad} findings, {time.time() - t0:.0f} s", flush=True)
 print(f"seeds {first}..{last}: {bad} findings")
